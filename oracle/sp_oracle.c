@@ -1,0 +1,717 @@
+/*
+ * sp_oracle.c -- CPU restatement of the reference's KSPSolve hot path and of
+ * the inputs it consumes.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (saddle_point_petsc_amd/, libspk.so) never
+ * links, imports or calls it.
+ *
+ * PARITY STATUS
+ *   - Input generator (A, f, boundary conditions): pinned against the
+ *     known-answer values of SURVEY.md Appendix B (element matrix, element
+ *     load, ||f||, ||u||, the M=4 solution), which were produced from the
+ *     reference's own element routines.
+ *   - Solver path (FGMRES / Gram-Schmidt / Jacobi / Schur fieldsplit):
+ *     PARITY UNPINNED.  The arithmetic lives in PETSc (>= 3.7, unpinned,
+ *     /root/reference/CMakeLists.txt:13), which is absent from this image and
+ *     cannot be built offline; the reference ships no tests or golden
+ *     vectors.  The solver below restates PETSc's published algorithm
+ *     (KSPFGMRES + KSPGMRESClassicalGramSchmidtOrthogonalization +
+ *     PCJACOBI + PCFIELDSPLIT/Schur with selfp) and is anchored on the
+ *     reference's call site /root/reference/src/SaddlePointProblem.c:65-72.
+ *   - The reference itself cannot be compiled here (needs PETSc headers and
+ *     libraries): there is no oracle/_ref.
+ *
+ * Reference lines each routine follows are cited at the routine.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction,
+ * so that golden fixtures reproduce bit-for-bit on any x86-64 host).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SPO_DIM 2
+#define SPO_NEN 4 /* nodes per element */
+#define SPO_DOF 2
+#define SPO_NGP 4
+#define SPO_EDOF (SPO_NEN * SPO_DOF)
+
+/* ------------------------------------------------------------------------- */
+/* 1. Element routines                                                        */
+/* ------------------------------------------------------------------------- */
+
+/* 2x2 Gauss rule with the reference's 11-digit abscissa, kept verbatim so that
+ * diag(A) carries the same 2.5e-13 truncation (Discretization.c:49-63). */
+static const double spo_gp[SPO_NGP][2] = {
+    {-0.57735026919, -0.57735026919},
+    {-0.57735026919, 0.57735026919},
+    {0.57735026919, 0.57735026919},
+    {0.57735026919, -0.57735026919}};
+static const double spo_gw[SPO_NGP] = {1.0, 1.0, 1.0, 1.0};
+
+/* Q1 shape functions, node order (-,-) (-,+) (+,+) (+,-)
+ * (Discretization.c:65-76). */
+static void spo_shape(const double xi[2], double N[SPO_NEN])
+{
+    const double a = xi[0], b = xi[1];
+    N[0] = 0.25 * (1.0 - a) * (1.0 - b);
+    N[1] = 0.25 * (1.0 - a) * (1.0 + b);
+    N[2] = 0.25 * (1.0 + a) * (1.0 + b);
+    N[3] = 0.25 * (1.0 + a) * (1.0 - b);
+}
+
+/* Reference-space gradients (Discretization.c:78-94). */
+static void spo_shape_grad(const double xi[2], double G[2][SPO_NEN])
+{
+    const double a = xi[0], b = xi[1];
+    G[0][0] = -0.25 * (1.0 - b);
+    G[0][1] = -0.25 * (1.0 + b);
+    G[0][2] = 0.25 * (1.0 + b);
+    G[0][3] = 0.25 * (1.0 - b);
+    G[1][0] = -0.25 * (1.0 - a);
+    G[1][1] = 0.25 * (1.0 - a);
+    G[1][2] = 0.25 * (1.0 + a);
+    G[1][3] = -0.25 * (1.0 + a);
+}
+
+/* Physical gradients and Jacobian determinant (Discretization.c:96-128);
+ * same accumulation order: Jac[c][d] += G[c][i] * X[i][d], i innermost. */
+static void spo_phys_grad(double G[2][SPO_NEN], const double *xe,
+                          double Gx[2][SPO_NEN], double *detJ)
+{
+    double J[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, iJ[2][2], det;
+    for (int c = 0; c < 2; ++c)
+        for (int d = 0; d < 2; ++d)
+            for (int i = 0; i < SPO_NEN; ++i)
+                J[c][d] += G[c][i] * xe[i * 2 + d];
+    det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    iJ[0][0] = J[1][1] / det;
+    iJ[0][1] = -J[0][1] / det;
+    iJ[1][0] = -J[1][0] / det;
+    iJ[1][1] = J[0][0] / det;
+    for (int i = 0; i < SPO_NEN; ++i) {
+        Gx[0][i] = iJ[0][0] * G[0][i] + iJ[0][1] * G[1][i];
+        Gx[1][i] = iJ[1][0] * G[0][i] + iJ[1][1] * G[1][i];
+    }
+    *detJ = det;
+}
+
+/* 8x8 stress-form stiffness, D = diag(2,2,1) (Discretization.c:293-332).
+ * Ke is ACCUMULATED into (caller zeroes it), index Ke[i + 8*j], k innermost,
+ * product evaluated as (B[k][i]*tD[k])*B[k][j]. */
+void spo_element_stiffness(const double *xe, const double *coeff, double *Ke)
+{
+    for (int p = 0; p < SPO_NGP; ++p) {
+        double G[2][SPO_NEN], Gx[2][SPO_NEN], det, tD[3], B[3][SPO_EDOF];
+        spo_shape_grad(spo_gp[p], G);
+        spo_phys_grad(G, xe, Gx, &det);
+        for (int i = 0; i < SPO_NEN; ++i) {
+            B[0][2 * i] = Gx[0][i];
+            B[0][2 * i + 1] = 0.0;
+            B[1][2 * i] = 0.0;
+            B[1][2 * i + 1] = Gx[1][i];
+            B[2][2 * i] = Gx[1][i];
+            B[2][2 * i + 1] = Gx[0][i];
+        }
+        tD[0] = 2.0 * spo_gw[p] * det * coeff[p];
+        tD[1] = 2.0 * spo_gw[p] * det * coeff[p];
+        tD[2] = spo_gw[p] * det * coeff[p];
+        for (int i = 0; i < SPO_EDOF; ++i)
+            for (int j = 0; j < SPO_EDOF; ++j)
+                for (int k = 0; k < 3; ++k)
+                    Ke[i + SPO_EDOF * j] += B[k][i] * tD[k] * B[k][j];
+    }
+}
+
+/* Body force (Discretization.c:397-402): constant (1,2). */
+static void spo_body_force(const double *x, double *fp)
+{
+    (void)x;
+    fp[0] = 1.0;
+    fp[1] = 2.0;
+}
+
+/* Element load vector (Discretization.c:334-374); Fe accumulated into. */
+void spo_element_load(const double *xe, double *Fe)
+{
+    for (int p = 0; p < SPO_NGP; ++p) {
+        double N[SPO_NEN], G[2][SPO_NEN], Gx[2][SPO_NEN], det, fac;
+        spo_shape(spo_gp[p], N);
+        spo_shape_grad(spo_gp[p], G);
+        spo_phys_grad(G, xe, Gx, &det);
+        fac = spo_gw[p] * det;
+        for (int i = 0; i < SPO_NEN; ++i) {
+            double xp[2] = {spo_gp[p][0], spo_gp[p][1]}, fp[2];
+            spo_body_force(xp, fp);
+            for (int c = 0; c < SPO_DOF; ++c)
+                Fe[i * SPO_DOF + c] += fac * N[i] * fp[c];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* 2. Grid, numbering, global assembly                                        */
+/* ------------------------------------------------------------------------- */
+
+/* Uniform node coordinate on [0,1] as DMDASetUniformCoordinates produces it
+ * (Discretization.c:25): x_i = 0 + i * (1/(m-1)). */
+static double spo_coord(int i, int m) { return 0.0 + (1.0 / (double)(m - 1)) * (double)i; }
+
+/* Corner gather in the INTENDED order (the commented block at
+ * Discretization.c:40-43; the live loop at :34-38 is the NaN defect A1):
+ * n0=(i,j) n1=(i,j+1) n2=(i+1,j+1) n3=(i+1,j). */
+static void spo_element_coords(int mx, int my, int ei, int ej, double *xe)
+{
+    xe[0] = spo_coord(ei, mx);     xe[1] = spo_coord(ej, my);
+    xe[2] = spo_coord(ei, mx);     xe[3] = spo_coord(ej + 1, my);
+    xe[4] = spo_coord(ei + 1, mx); xe[5] = spo_coord(ej + 1, my);
+    xe[6] = spo_coord(ei + 1, mx); xe[7] = spo_coord(ej, my);
+}
+
+/* Element equation numbers (Discretization.c:377-395) in the natural
+ * single-rank ordering row = (j*mx + i)*2 + c. */
+static void spo_element_eqn(int mx, int ei, int ej, int32_t *eq)
+{
+    const int ni[4] = {ei, ei, ei + 1, ei + 1};
+    const int nj[4] = {ej, ej + 1, ej + 1, ej};
+    for (int a = 0; a < SPO_NEN; ++a)
+        for (int c = 0; c < SPO_DOF; ++c)
+            eq[a * SPO_DOF + c] = (int32_t)((nj[a] * mx + ni[a]) * SPO_DOF + c);
+}
+
+/* Sizes of the (0,0) block for an mx x my node grid. */
+void spo_grid_sizes(int mx, int my, int64_t *nrows, int64_t *nnz)
+{
+    *nrows = (int64_t)2 * mx * my;
+    *nnz = (int64_t)4 * (3 * (int64_t)mx - 2) * (3 * (int64_t)my - 2);
+}
+
+/* Non-zero structure DMCreateMatrix preallocates for a dof-2, width-1 BOX
+ * stencil DMDA (SaddlePointProblem.c:42, Discretization.c:17): every node
+ * couples to its <=9 neighbours x 2 dof, columns ascending.  Values zeroed. */
+void spo_pattern(int mx, int my, int32_t *rowptr, int32_t *colidx, double *val)
+{
+    int64_t k = 0;
+    for (int j = 0; j < my; ++j)
+        for (int i = 0; i < mx; ++i)
+            for (int c = 0; c < SPO_DOF; ++c) {
+                rowptr[(j * mx + i) * SPO_DOF + c] = (int32_t)k;
+                for (int dj = -1; dj <= 1; ++dj) {
+                    if (j + dj < 0 || j + dj >= my) continue;
+                    for (int di = -1; di <= 1; ++di) {
+                        if (i + di < 0 || i + di >= mx) continue;
+                        for (int d = 0; d < SPO_DOF; ++d) {
+                            colidx[k] = (int32_t)(((j + dj) * mx + (i + di)) * SPO_DOF + d);
+                            val[k] = 0.0;
+                            ++k;
+                        }
+                    }
+                }
+            }
+    rowptr[2 * mx * my] = (int32_t)k;
+}
+
+static int64_t spo_find(const int32_t *rowptr, const int32_t *colidx, int32_t r, int32_t c)
+{
+    int64_t lo = rowptr[r], hi = rowptr[r + 1] - 1;
+    while (lo <= hi) {
+        int64_t mid = (lo + hi) / 2;
+        if (colidx[mid] == c) return mid;
+        if (colidx[mid] < c) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+/* Global operator: element loop j outer / i inner with ADD_VALUES
+ * (Discretization.c:130-172).  Structural zeros stay stored. */
+int spo_assemble_A(int mx, int my, int32_t *rowptr, int32_t *colidx, double *val)
+{
+    spo_pattern(mx, my, rowptr, colidx, val);
+    for (int ej = 0; ej < my - 1; ++ej)
+        for (int ei = 0; ei < mx - 1; ++ei) {
+            double xe[8], coeff[4] = {1.0, 1.0, 1.0, 1.0}, Ke[64];
+            int32_t eq[8];
+            memset(Ke, 0, sizeof Ke);
+            spo_element_coords(mx, my, ei, ej, xe);
+            spo_element_stiffness(xe, coeff, Ke);
+            spo_element_eqn(mx, ei, ej, eq);
+            /* MatSetValuesStencil takes the 8x8 block row-major: entry
+             * (row a, col b) is Ae[a*8+b] (Discretization.c:165). */
+            for (int a = 0; a < 8; ++a)
+                for (int b = 0; b < 8; ++b) {
+                    int64_t k = spo_find(rowptr, colidx, eq[a], eq[b]);
+                    if (k < 0) return 1;
+                    val[k] += Ke[a * 8 + b];
+                }
+        }
+    return 0;
+}
+
+/* Global load (Discretization.c:174-227). */
+int spo_assemble_f(int mx, int my, double *f)
+{
+    memset(f, 0, sizeof(double) * 2 * (size_t)mx * my);
+    for (int ej = 0; ej < my - 1; ++ej)
+        for (int ei = 0; ei < mx - 1; ++ei) {
+            double xe[8], Fe[8];
+            int32_t eq[8];
+            memset(Fe, 0, sizeof Fe);
+            spo_element_coords(mx, my, ei, ej, xe);
+            spo_element_load(xe, Fe);
+            spo_element_eqn(mx, ei, ej, eq);
+            for (int a = 0; a < 8; ++a) f[eq[a]] += Fe[a];
+        }
+    return 0;
+}
+
+static int spo_is_boundary(int mx, int my, int i, int j)
+{
+    return i == 0 || i == mx - 1 || j == 0 || j == my - 1;
+}
+
+/* Homogeneous Dirichlet on all four sides (Discretization.c:229-274):
+ * f_bc = 0 (:264), then MatZeroRowsColumns(A, bc, 1.0, NULL, NULL) (:268):
+ * rows AND columns zeroed, unit diagonal, no right-hand-side correction
+ * because x and b are NULL.  The non-zero structure is kept. */
+int spo_apply_bc(int mx, int my, const int32_t *rowptr, const int32_t *colidx,
+                 double *val, double *f)
+{
+    const int32_t n = 2 * mx * my;
+    for (int32_t r = 0; r < n; ++r) {
+        const int node = r / 2, i = node % mx, j = node / mx;
+        const int rb = spo_is_boundary(mx, my, i, j);
+        if (rb && f) f[r] = 0.0;
+        for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const int cn = colidx[k] / 2;
+            const int cb = spo_is_boundary(mx, my, cn % mx, cn / mx);
+            if (rb || cb) val[k] = (colidx[k] == r) ? 1.0 : 0.0;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 3. Constraint block -- BUILD-DEFINED (the reference's assemblers are empty  */
+/*    stubs, Discretization.c:277-290; only the shape 4 x nCols and len(g)=4   */
+/*    are given, SaddlePointProblem.c:49,52).  Definition: SURVEY.md App. B.   */
+/* ------------------------------------------------------------------------- */
+
+/* nnz of B: 4 rows x (interior nodes). */
+int64_t spo_constraint_nnz(int mx, int my) { return (int64_t)4 * (mx - 2) * (my - 2); }
+
+/* Rows: b0 = x-component mean, b1 = y-component mean, b2 = x-moment of Ux,
+ * b3 = y-moment of Uy, with lumped nodal weights hx*hy on interior nodes;
+ * Dirichlet columns are dropped (consistent with Discretization.c:268). */
+int spo_assemble_B(int mx, int my, int32_t *rowptr, int32_t *colidx, double *val)
+{
+    const double hx = 1.0 / (double)(mx - 1), hy = 1.0 / (double)(my - 1);
+    const double w = hx * hy;
+    int64_t k = 0;
+    for (int r = 0; r < 4; ++r) {
+        rowptr[r] = (int32_t)k;
+        for (int j = 1; j < my - 1; ++j)
+            for (int i = 1; i < mx - 1; ++i) {
+                const int c = r & 1; /* rows 0,2 act on Ux; rows 1,3 on Uy */
+                double v = w;
+                if (r == 2) v = w * (spo_coord(i, mx) - 0.5);
+                if (r == 3) v = w * (spo_coord(j, my) - 0.5);
+                colidx[k] = (int32_t)((j * mx + i) * 2 + c);
+                val[k] = v;
+                ++k;
+            }
+    }
+    rowptr[4] = (int32_t)k;
+    return 0;
+}
+
+/* Constraint right-hand side; g = 0 is degenerate. */
+void spo_constraint_rhs(double *g)
+{
+    g[0] = 1e-2; g[1] = -2e-2; g[2] = 3e-3; g[3] = 1e-3;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 4. Kernels of the solve: PETSc AIJ/Vec semantics (external) */
+/* ------------------------------------------------------------------------- */
+
+static int spo_threads = 1;
+void spo_set_threads(int t)
+{
+    spo_threads = t > 0 ? t : 1;
+#ifdef _OPENMP
+    omp_set_num_threads(spo_threads);
+#endif
+}
+int spo_get_threads(void) { return spo_threads; }
+
+/* y = A x, CSR, one sequential sum per row (MatMult_SeqAIJ). */
+void spo_spmv(int32_t n, const int32_t *rowptr, const int32_t *colidx,
+              const double *val, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static) if (spo_threads > 1)
+    for (int32_t r = 0; r < n; ++r) {
+        double s = 0.0;
+        for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) s += val[k] * x[colidx[k]];
+        y[r] = s;
+    }
+}
+
+/* y += A^T x for a short-and-wide CSR block (MatMultTransposeAdd_SeqAIJ). */
+void spo_spmv_t_add(int32_t nrows, const int32_t *rowptr, const int32_t *colidx,
+                    const double *val, const double *x, double *y)
+{
+    for (int32_t r = 0; r < nrows; ++r) {
+        const double xr = x[r];
+#pragma omp parallel for schedule(static) if (spo_threads > 1)
+        for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) y[colidx[k]] += val[k] * xr;
+    }
+}
+
+static double spo_dot(int64_t n, const double *x, const double *y)
+{
+    double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s) if (spo_threads > 1)
+    for (int64_t i = 0; i < n; ++i) s += x[i] * y[i];
+    return s;
+}
+double spo_vec_dot(int64_t n, const double *x, const double *y) { return spo_dot(n, x, y); }
+double spo_vec_norm(int64_t n, const double *x) { return sqrt(spo_dot(n, x, x)); }
+
+static void spo_axpy(int64_t n, double a, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static) if (spo_threads > 1)
+    for (int64_t i = 0; i < n; ++i) y[i] += a * x[i];
+}
+static void spo_scale(int64_t n, double a, double *x)
+{
+#pragma omp parallel for schedule(static) if (spo_threads > 1)
+    for (int64_t i = 0; i < n; ++i) x[i] *= a;
+}
+static void spo_copy(int64_t n, const double *x, double *y) { memcpy(y, x, sizeof(double) * (size_t)n); }
+
+/* ------------------------------------------------------------------------- */
+/* 5. Operator K = A  or  K = [A B^T; B 0]   (MatNest sketched at             */
+/*    SaddlePointProblem.c:45-60) and the preconditioners                      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t n;
+    const int32_t *a_rowptr, *a_colidx;
+    const double *a_val;
+    int32_t m; /* rows of B; 0 = no constraint block */
+    const int32_t *b_rowptr, *b_colidx;
+    const double *b_val;
+} spo_operator;
+
+enum { SPO_PC_NONE = 0, SPO_PC_JACOBI = 1, SPO_PC_SCHUR = 2 };
+enum { SPO_SCHUR_DIAG = 0, SPO_SCHUR_LOWER = 1, SPO_SCHUR_UPPER = 2, SPO_SCHUR_FULL = 3 };
+
+typedef struct {
+    int32_t pc_type, schur_fact, restart, max_it;
+    double rtol, abstol, dtol;
+    int32_t guess_nonzero, threads;
+} spo_options;
+
+typedef struct {
+    int32_t its, reason;
+    double rnorm, rnorm0;
+    int32_t hist_len, pad;
+} spo_result;
+
+/* y = K x (MatMult_Nest over MatMult_SeqAIJ blocks). */
+void spo_apply_K(const spo_operator *op, const double *x, double *y)
+{
+    spo_spmv(op->n, op->a_rowptr, op->a_colidx, op->a_val, x, y);
+    if (op->m > 0) {
+        spo_spmv_t_add(op->m, op->b_rowptr, op->b_colidx, op->b_val, x + op->n, y);
+        spo_spmv(op->m, op->b_rowptr, op->b_colidx, op->b_val, x, y + op->n);
+    }
+}
+
+/* diag(A)^-1 with PCJACOBI's "zero diagonal -> 1" rule. */
+void spo_jacobi_setup(const spo_operator *op, double *dinv)
+{
+    for (int32_t r = 0; r < op->n; ++r) {
+        double d = 0.0;
+        for (int32_t k = op->a_rowptr[r]; k < op->a_rowptr[r + 1]; ++k)
+            if (op->a_colidx[k] == r) d = op->a_val[k];
+        dinv[r] = (d == 0.0) ? 1.0 : 1.0 / d;
+    }
+}
+
+/* Shat_r = sum_c B_rc^2 dinv_c = diag(B diag(A)^-1 B^T)  (selfp, diagonal
+ * kept; north_star's S^ ).  Also the full 4x4 G = B diag(A)^-1 B^T. */
+void spo_schur_setup(const spo_operator *op, const double *dinv, double *shat, double *G)
+{
+    const int32_t m = op->m;
+    double *row = (double *)calloc((size_t)op->n, sizeof(double));
+    for (int32_t r = 0; r < m; ++r) {
+        for (int32_t k = op->b_rowptr[r]; k < op->b_rowptr[r + 1]; ++k)
+            row[op->b_colidx[k]] = op->b_val[k] * dinv[op->b_colidx[k]];
+        for (int32_t s = 0; s < m; ++s) {
+            double acc = 0.0;
+            for (int32_t k = op->b_rowptr[s]; k < op->b_rowptr[s + 1]; ++k)
+                acc += op->b_val[k] * row[op->b_colidx[k]];
+            if (G) G[r * m + s] = acc;
+            if (r == s) shat[r] = acc;
+        }
+        for (int32_t k = op->b_rowptr[r]; k < op->b_rowptr[r + 1]; ++k) row[op->b_colidx[k]] = 0.0;
+    }
+    free(row);
+}
+
+typedef struct {
+    const spo_operator *op;
+    int pc_type, schur_fact;
+    double *dinv, *shat, *t0;
+} spo_pc;
+
+/* z = M^-1 v.  Jacobi: PCApply_Jacobi.  Schur: PCApply_FieldSplit_Schur with
+ * A^ ^-1 = diag(A)^-1 and S~ = -S^ ; DIAG flips the sign of the Schur block
+ * (PETSc's default schur scale -1): y1 = +S^ ^-1 x1 ... see SURVEY App. C:
+ *   DIAG : y0 = D x0 ; y1 = -S~^-1 x1 = S^ ^-1 x1
+ *   LOWER: y0 = D x0 ; y1 = S~^-1 (x1 - B y0)
+ *   UPPER: y1 = S~^-1 x1 ; y0 = D (x0 - B^T y1)
+ *   FULL : y0 = D x0 ; y1 = S~^-1 (x1 - B y0) ; y0 -= D B^T y1          */
+void spo_pc_apply(const spo_pc *pc, const double *x, double *y)
+{
+    const spo_operator *op = pc->op;
+    const int32_t n = op->n, m = op->m;
+    if (pc->pc_type == SPO_PC_NONE) { spo_copy((int64_t)n + m, x, y); return; }
+    if (pc->pc_type == SPO_PC_JACOBI) {
+        for (int32_t i = 0; i < n; ++i) y[i] = x[i] * pc->dinv[i];
+        for (int32_t i = 0; i < m; ++i) y[n + i] = x[n + i]; /* zero diagonal -> 1 */
+        return;
+    }
+    /* Schur */
+    const double *x0 = x, *x1 = x + n;
+    double *y0 = y, *y1 = y + n;
+    double t[16];
+    switch (pc->schur_fact) {
+    case SPO_SCHUR_DIAG:
+        for (int32_t i = 0; i < n; ++i) y0[i] = x0[i] * pc->dinv[i];
+        for (int32_t r = 0; r < m; ++r) y1[r] = x1[r] / pc->shat[r];
+        break;
+    case SPO_SCHUR_LOWER:
+        for (int32_t i = 0; i < n; ++i) y0[i] = x0[i] * pc->dinv[i];
+        spo_spmv(m, op->b_rowptr, op->b_colidx, op->b_val, y0, t);
+        for (int32_t r = 0; r < m; ++r) y1[r] = -(x1[r] - t[r]) / pc->shat[r];
+        break;
+    case SPO_SCHUR_UPPER:
+        for (int32_t r = 0; r < m; ++r) y1[r] = -x1[r] / pc->shat[r];
+        memset(pc->t0, 0, sizeof(double) * (size_t)n);
+        spo_spmv_t_add(m, op->b_rowptr, op->b_colidx, op->b_val, y1, pc->t0);
+        for (int32_t i = 0; i < n; ++i) y0[i] = (x0[i] - pc->t0[i]) * pc->dinv[i];
+        break;
+    default: /* FULL */
+        for (int32_t i = 0; i < n; ++i) y0[i] = x0[i] * pc->dinv[i];
+        spo_spmv(m, op->b_rowptr, op->b_colidx, op->b_val, y0, t);
+        for (int32_t r = 0; r < m; ++r) y1[r] = -(x1[r] - t[r]) / pc->shat[r];
+        memset(pc->t0, 0, sizeof(double) * (size_t)n);
+        spo_spmv_t_add(m, op->b_rowptr, op->b_colidx, op->b_val, y1, pc->t0);
+        for (int32_t i = 0; i < n; ++i) y0[i] -= pc->t0[i] * pc->dinv[i];
+        break;
+    }
+}
+
+/* Stand-alone PC application for tests: sets up, applies once, tears down. */
+int spo_pc_apply_once(const spo_operator *op, int pc_type, int schur_fact,
+                      const double *x, double *y)
+{
+    spo_pc pc = {op, pc_type, schur_fact, NULL, NULL, NULL};
+    pc.dinv = (double *)malloc(sizeof(double) * (size_t)op->n);
+    pc.t0 = (double *)malloc(sizeof(double) * (size_t)op->n);
+    pc.shat = (double *)calloc(16, sizeof(double));
+    spo_jacobi_setup(op, pc.dinv);
+    if (op->m > 0) spo_schur_setup(op, pc.dinv, pc.shat, NULL);
+    spo_pc_apply(&pc, x, y);
+    free(pc.dinv); free(pc.t0); free(pc.shat);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 6. FGMRES(m), classical Gram-Schmidt without refinement, right (flexible)   */
+/*    preconditioning, unpreconditioned residual norm, KSPConvergedDefault     */
+/*    -- PETSc KSPSolve_FGMRES / KSPFGMRESCycle / KSPFGMRESUpdateHessenberg /  */
+/*    KSPFGMRESBuildSoln as published (external).        */
+/*    This is what the call at SaddlePointProblem.c:70 executes when run with  */
+/*    -ksp_type fgmres.                                                        */
+/* ------------------------------------------------------------------------- */
+
+enum {
+    SPO_CONVERGED_RTOL = 2, SPO_CONVERGED_ATOL = 3, SPO_CONVERGED_HAPPY = 7,
+    SPO_DIVERGED_NULL = -2, SPO_DIVERGED_ITS = -3, SPO_DIVERGED_DTOL = -4,
+    SPO_DIVERGED_BREAKDOWN = -5, SPO_DIVERGED_NANORINF = -9
+};
+
+static int spo_converged(double rnorm, double ttol, double abstol, double dtol, double rnorm0)
+{
+    if (isnan(rnorm) || isinf(rnorm)) return SPO_DIVERGED_NANORINF;
+    if (rnorm <= ttol) return (rnorm < abstol) ? SPO_CONVERGED_ATOL : SPO_CONVERGED_RTOL;
+    if (rnorm >= dtol * rnorm0) return SPO_DIVERGED_DTOL;
+    return 0;
+}
+
+int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
+               double *x, spo_result *res, double *history, int32_t history_cap)
+{
+    const int64_t N = (int64_t)op->n + op->m;
+    const int mk = opt->restart;
+    const double haptol = 1e-30;
+    int its = 0, reason = 0, hist = 0;
+    double rnorm = 0.0, rnorm0 = 0.0, ttol = 0.0;
+
+    spo_set_threads(opt->threads);
+
+    double *V = (double *)malloc(sizeof(double) * (size_t)N * (mk + 1));
+    double *Z = (double *)malloc(sizeof(double) * (size_t)N * mk);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)N);
+    double *H = (double *)calloc((size_t)(mk + 2) * (mk + 1), sizeof(double)); /* H[i + (mk+2)*j] */
+    double *cc = (double *)calloc((size_t)mk + 1, sizeof(double));
+    double *ss = (double *)calloc((size_t)mk + 1, sizeof(double));
+    double *rs = (double *)calloc((size_t)mk + 2, sizeof(double));
+    double *nrs = (double *)calloc((size_t)mk + 1, sizeof(double));
+    double *lhh = (double *)calloc((size_t)mk + 1, sizeof(double));
+    spo_pc pc = {op, opt->pc_type, opt->schur_fact, NULL, NULL, NULL};
+    pc.dinv = (double *)malloc(sizeof(double) * (size_t)op->n);
+    pc.t0 = (double *)malloc(sizeof(double) * (size_t)op->n);
+    pc.shat = (double *)calloc(16, sizeof(double));
+    spo_jacobi_setup(op, pc.dinv);
+    if (op->m > 0) spo_schur_setup(op, pc.dinv, pc.shat, NULL);
+#define HH(i, j) H[(i) + (size_t)(mk + 2) * (j)]
+#define VV(j) (V + (size_t)N * (j))
+#define ZZ(j) (Z + (size_t)N * (j))
+
+    /* KSPConvergedDefault: ttol = max(rtol*||b||, abstol). */
+    {
+        const double bnorm = spo_vec_norm(N, b);
+        ttol = fmax(opt->rtol * bnorm, opt->abstol);
+    }
+
+    /* Initial residual into V0. */
+    if (!opt->guess_nonzero) {
+        memset(x, 0, sizeof(double) * (size_t)N);
+        spo_copy(N, b, VV(0));
+    } else {
+        spo_apply_K(op, x, tmp);
+        spo_copy(N, b, VV(0));
+        spo_axpy(N, -1.0, tmp, VV(0));
+    }
+
+    while (!reason) {
+        /* ---- one restart cycle (KSPFGMRESCycle) ---- */
+        int loc = 0, hapend = 0;
+        rnorm = spo_vec_norm(N, VV(0));
+        if (its == 0) rnorm0 = rnorm;
+        if (history && hist < history_cap && its == 0) history[hist++] = rnorm;
+        reason = spo_converged(rnorm, ttol, opt->abstol, opt->dtol, rnorm0);
+        if (reason) break;
+        spo_scale(N, 1.0 / rnorm, VV(0));
+        rs[0] = rnorm;
+
+        while (!reason && loc < mk && its < opt->max_it) {
+            double tt, hapbnd;
+            /* z_j = M^-1 v_j ; w = K z_j */
+            spo_pc_apply(&pc, VV(loc), ZZ(loc));
+            spo_apply_K(op, ZZ(loc), VV(loc + 1));
+            /* classical Gram-Schmidt: VecMDot, negate, VecMAXPY */
+            for (int j = 0; j <= loc; ++j) lhh[j] = -spo_dot(N, VV(loc + 1), VV(j));
+            for (int j = 0; j <= loc; ++j) spo_axpy(N, lhh[j], VV(j), VV(loc + 1));
+            for (int j = 0; j <= loc; ++j) HH(j, loc) = -lhh[j];
+            tt = spo_vec_norm(N, VV(loc + 1));
+            /* happy breakdown test */
+            hapbnd = fabs(tt / rs[loc]);
+            if (hapbnd > haptol) hapbnd = haptol;
+            if (tt > hapbnd) spo_scale(N, 1.0 / tt, VV(loc + 1));
+            else hapend = 1;
+            HH(loc + 1, loc) = tt;
+            /* Givens update of the new column (KSPFGMRESUpdateHessenberg) */
+            for (int j = 1; j <= loc; ++j) {
+                const double h0 = HH(j - 1, loc), h1 = HH(j, loc);
+                HH(j - 1, loc) = cc[j - 1] * h0 + ss[j - 1] * h1;
+                HH(j, loc) = cc[j - 1] * h1 - ss[j - 1] * h0;
+            }
+            if (!hapend) {
+                const double h0 = HH(loc, loc), h1 = HH(loc + 1, loc);
+                const double d = sqrt(h0 * h0 + h1 * h1);
+                if (d == 0.0) { reason = SPO_DIVERGED_NULL; break; }
+                cc[loc] = h0 / d;
+                ss[loc] = h1 / d;
+                rs[loc + 1] = -ss[loc] * rs[loc];
+                rs[loc] = cc[loc] * rs[loc];
+                HH(loc, loc) = cc[loc] * h0 + ss[loc] * h1;
+                rnorm = fabs(rs[loc + 1]);
+            } else {
+                rnorm = 0.0;
+            }
+            ++loc;
+            ++its;
+            if (history && hist < history_cap) history[hist++] = rnorm;
+            reason = spo_converged(rnorm, ttol, opt->abstol, opt->dtol, rnorm0);
+            if (hapend) {
+                if (!reason) reason = SPO_DIVERGED_BREAKDOWN;
+                break;
+            }
+        }
+        if (!reason && its >= opt->max_it) reason = SPO_DIVERGED_ITS;
+
+        /* x += Z y, y from back substitution (KSPFGMRESBuildSoln) */
+        if (loc > 0) {
+            int bad = 0;
+            for (int k = loc - 1; k >= 0; --k) {
+                double t = rs[k];
+                for (int j = k + 1; j < loc; ++j) t -= HH(k, j) * nrs[j];
+                if (HH(k, k) == 0.0) { bad = 1; break; }
+                nrs[k] = t / HH(k, k);
+            }
+            if (bad) { if (reason >= 0) reason = SPO_DIVERGED_BREAKDOWN; break; }
+            memset(tmp, 0, sizeof(double) * (size_t)N);
+            for (int j = 0; j < loc; ++j) spo_axpy(N, nrs[j], ZZ(j), tmp);
+            spo_axpy(N, 1.0, tmp, x);
+        }
+        if (reason) break;
+        /* true residual for the next cycle (KSPFGMRESResidual) */
+        spo_apply_K(op, x, tmp);
+        spo_copy(N, b, VV(0));
+        spo_axpy(N, -1.0, tmp, VV(0));
+    }
+
+    res->its = its;
+    res->reason = reason;
+    res->rnorm = rnorm;
+    res->rnorm0 = rnorm0;
+    res->hist_len = hist;
+    res->pad = 0;
+#undef HH
+#undef VV
+#undef ZZ
+    free(V); free(Z); free(tmp); free(H); free(cc); free(ss); free(rs); free(nrs); free(lhh);
+    free(pc.dinv); free(pc.t0); free(pc.shat);
+    return 0;
+}
+
+/* Timing helper for bench.py's cpu_baseline leg: `reps` applications of the
+ * A-block SpMV; returns seconds (wall). */
+#include <time.h>
+static double spo_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+double spo_time_spmv(int32_t n, const int32_t *rowptr, const int32_t *colidx,
+                     const double *val, const double *x, double *y, int reps, int threads)
+{
+    spo_set_threads(threads);
+    spo_spmv(n, rowptr, colidx, val, x, y); /* warm */
+    const double t0 = spo_now();
+    for (int r = 0; r < reps; ++r) spo_spmv(n, rowptr, colidx, val, x, y);
+    return spo_now() - t0;
+}
+double spo_wtime(void) { return spo_now(); }
