@@ -1,0 +1,189 @@
+/*
+ * spk.h -- C ABI of libspk.so: the MI355X-native replacement for what
+ * KSPSolve() executes at /root/reference/src/SaddlePointProblem.c:70.
+ *
+ * The reference reaches its solver through six PETSc calls
+ * (SaddlePointProblem.c:65-72):
+ *     KSPCreate, KSPSetOperators(ksp,A,A), KSPSetFromOptions, KSPSetUp,
+ *     KSPSolve(ksp,f,u), KSPDestroy.
+ * Everything below KSPSolve (MatMult_*AIJ, PCApply_Jacobi,
+ * PCApply_FieldSplit_Schur, KSPSolve_FGMRES, VecMDot/VecMAXPY/VecNorm,
+ * VecScatter halo, MPI_Allreduce) runs inside PETSc.  This header is what a
+ * PETSc plugin (PCSHELL / MATSHELL / KSPRegister'd type, see
+ * plugin/spk_petsc.c and INTEGRATION.md) binds instead.  Plain C: opaque
+ * context, raw CSR / vector pointers, sizes, int status.  No PETSc, no torch.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SPK_ERR_* otherwise;
+ *     spk_last_error() then holds a message.  Non-convergence is NOT an error:
+ *     it is reported through spk_result.reason (PETSc KSPConvergedReason
+ *     values), as KSPSolve does.
+ *   - the caller owns every array it passes; the library copies at
+ *     spk_set_block() and never keeps host pointers.  All device memory
+ *     belongs to the context and is released by spk_destroy().
+ *   - one context per KSP; no global state; a context is driven by one host
+ *     thread at a time; every call is synchronous at return.
+ *   - vectors are FP64.  A system vector is [u ; lambda]: the rank's n_local
+ *     rows of the (0,0) block followed by ALL m constraint multipliers
+ *     (replicated on every rank).  m = 0 when no constraint block is set.
+ *   - `mem` arguments: SPK_MEM_HOST or SPK_MEM_DEVICE for the x/y/b pointers.
+ */
+#ifndef SPK_H
+#define SPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPK_VERSION 100
+
+typedef struct spk_ctx spk_ctx;
+
+enum { SPK_OK = 0, SPK_ERR_ARG = -1, SPK_ERR_HIP = -2, SPK_ERR_STATE = -3,
+       SPK_ERR_COMM = -4, SPK_ERR_NOMEM = -5, SPK_ERR_UNSUPPORTED = -6 };
+
+enum { SPK_MEM_HOST = 0, SPK_MEM_DEVICE = 1 };
+
+/* Blocks of the nest K = [A00 A01; A10 0] sketched at
+ * SaddlePointProblem.c:45-60 (MatGetSize/MatSetSizes(B, 4, nCols)).
+ * A01 is always A10^T and is derived by the library. */
+enum { SPK_BLOCK_A00 = 0, SPK_BLOCK_A10 = 1 };
+
+/* -pc_type {none,jacobi,fieldsplit(schur)} as read by KSPSetFromOptions
+ * (SaddlePointProblem.c:67). */
+enum { SPK_PC_NONE = 0, SPK_PC_JACOBI = 1, SPK_PC_SCHUR = 2 };
+/* -pc_fieldsplit_schur_fact_type */
+enum { SPK_SCHUR_DIAG = 0, SPK_SCHUR_LOWER = 1, SPK_SCHUR_UPPER = 2, SPK_SCHUR_FULL = 3 };
+/* -ksp_gmres_{classical,modified}gramschmidt */
+enum { SPK_ORTHOG_CGS = 0, SPK_ORTHOG_MGS = 1 };
+/* SpMV storage of the (0,0) block */
+enum { SPK_SPMV_CSR = 0 };
+
+/* KSPConvergedReason values (PETSc numbering). */
+enum { SPK_CONVERGED_RTOL = 2, SPK_CONVERGED_ATOL = 3, SPK_CONVERGED_ITS = 4,
+       SPK_CONVERGED_HAPPY_BREAKDOWN = 7, SPK_DIVERGED_NULL = -2,
+       SPK_DIVERGED_ITS = -3, SPK_DIVERGED_DTOL = -4, SPK_DIVERGED_BREAKDOWN = -5,
+       SPK_DIVERGED_NANORINF = -9, SPK_ITERATING = 0 };
+
+/* Solver options = the slice of the PETSc options database the reference
+ * exposes through KSPSetFromOptions (SaddlePointProblem.c:67).  Fill with
+ * spk_default_opts() first (PETSc defaults). */
+typedef struct spk_opts {
+    int32_t restart;        /* -ksp_gmres_restart            (30)    */
+    int32_t max_it;         /* -ksp_max_it                   (10000) */
+    double rtol;            /* -ksp_rtol                     (1e-5)  */
+    double abstol;          /* -ksp_atol                     (1e-50) */
+    double dtol;            /* -ksp_divtol                   (1e4)   */
+    int32_t guess_nonzero;  /* -ksp_initial_guess_nonzero    (0)     */
+    int32_t orthog;         /* SPK_ORTHOG_*                  (CGS)   */
+    int32_t check_every;    /* host looks at the device convergence word every
+                               this many iterations; 0 = once per restart cycle.
+                               The iterate never depends on it.       */
+    int32_t fused;          /* 1: fused PC+operator kernels where the PC allows,
+                               0: PCApply and MatMult as separate steps */
+    int32_t reserved[4];
+} spk_opts;
+
+typedef struct spk_result {
+    int32_t its;            /* KSPGetIterationNumber   */
+    int32_t reason;         /* KSPGetConvergedReason   */
+    double rnorm;           /* KSPGetResidualNorm (unpreconditioned estimate) */
+    double rnorm0;          /* residual norm at iteration 0 */
+    int32_t hist_len;       /* entries written to history[] */
+    int32_t cycles;         /* restart cycles executed */
+    double solve_seconds;   /* wall time inside spk_fgmres, upload excluded */
+} spk_result;
+
+/* ---- lifetime (KSPCreate / KSPDestroy, SaddlePointProblem.c:65,72) ------- */
+int spk_create(spk_ctx **ctx, int device);
+int spk_destroy(spk_ctx *ctx);
+/* Message of the last failure on ctx (ctx may be NULL: last spk_create error). */
+const char *spk_last_error(const spk_ctx *ctx);
+int spk_version(void);
+void spk_default_opts(spk_opts *opts);
+
+/* ---- multi-GPU wiring (replaces PETSC_COMM_WORLD, SaddlePointProblem.c:65) */
+/* One process per GPU: rank 0 calls spk_comm_unique_id, the host side
+ * broadcasts the 128 bytes (MPI_Bcast in a PETSc plugin, torch.distributed in
+ * bench.py), every rank calls spk_comm_init_rccl before spk_set_block. */
+int spk_comm_unique_id(void *id128);
+int spk_comm_init_rccl(spk_ctx *ctx, int rank, int nranks, const void *id128);
+/* In-process logical ranks on one device (parity tests of the partitioned
+ * algorithm on a 1-GPU box): a group is shared by `nranks` contexts, each
+ * driven by its own host thread. */
+typedef struct spk_local_group spk_local_group;
+int spk_local_group_create(spk_local_group **grp, int nranks);
+int spk_local_group_destroy(spk_local_group *grp);
+int spk_comm_init_local(spk_ctx *ctx, spk_local_group *grp, int rank);
+
+/* ---- operators (KSPSetOperators, SaddlePointProblem.c:66) ---------------- */
+/* CSR rows [row_begin, row_begin+nrows_local) of a block with ncols_global
+ * columns; colidx are GLOBAL column numbers, int32 (PetscInt), ascending or
+ * not.  The library splits diagonal / off-rank columns and builds the halo
+ * plan (what MatMPIAIJ + VecScatter do in the reference's PETSc).
+ *   A00: the rank's row slab of A; rows must tile [0,n) in rank order.
+ *   A10: ALL m rows of B restricted to the rank's owned columns
+ *        (column-partitioned like the rows of A00); pass row_begin = 0,
+ *        nrows_local = m. */
+int spk_set_block(spk_ctx *ctx, int which, int64_t row_begin, int32_t nrows_local,
+                  int64_t ncols_global, const int32_t *rowptr, const int32_t *colidx,
+                  const double *val);
+
+/* ---- preconditioner (KSPSetUp, SaddlePointProblem.c:68) ------------------ */
+/* Builds diag(A)^-1 and, for SPK_PC_SCHUR, S^ = diag(B diag(A)^-1 B^T). */
+int spk_pc_setup(spk_ctx *ctx, int pc_type, int schur_fact);
+/* Copies S^ (m doubles) to the host, for inspection. */
+int spk_get_schur_diag(spk_ctx *ctx, double *shat);
+int spk_get_jacobi_diag(spk_ctx *ctx, double *dinv /* n_local */);
+
+/* ---- the three plug points ------------------------------------------------ */
+/* MATSHELL:  y = K x.   PCSHELL: y = M^-1 x.   Lengths n_local + m. */
+int spk_mult(spk_ctx *ctx, const double *x, double *y, int mem);
+int spk_pc_apply(spk_ctx *ctx, const double *x, double *y, int mem);
+/* KSP type: the whole KSPSolve (SaddlePointProblem.c:70) on the device.
+ * b, x: n_local + m values.  history (may be NULL) receives the residual norm
+ * per iteration, starting with iteration 0. */
+int spk_fgmres(spk_ctx *ctx, const double *b, double *x, int mem, const spk_opts *opts,
+               spk_result *result, double *history, int32_t history_cap);
+
+/* ---- sizes ---------------------------------------------------------------- */
+int spk_get_sizes(const spk_ctx *ctx, int64_t *n_global, int32_t *n_local, int32_t *m,
+                  int64_t *nnz_local, int32_t *n_ghost);
+
+/* ---- single kernels through the ABI (parity tests, bench.py) -------------- */
+/* h[i] = V_i . w  (i < nv), V given as nv vectors of length n with stride ldv
+ * (VecMDot).  Host pointers. */
+int spk_kernel_mdot(spk_ctx *ctx, int64_t n, int32_t nv, const double *V, int64_t ldv,
+                    const double *w, double *h);
+/* w += sum_i a[i] V_i   (VecMAXPY); returns ||w_new||^2 in *nrm2 if non-NULL. */
+int spk_kernel_maxpy(spk_ctx *ctx, int64_t n, int32_t nv, const double *a, const double *V,
+                     int64_t ldv, double *w, double *nrm2);
+/* Times `reps` launches of the A-block SpMV kernel with HIP events on the
+ * context's stream after `warmup` untimed launches; *ms_per_launch = average.
+ * x is a deterministic fill sin(0.37 i). */
+int spk_time_spmv(spk_ctx *ctx, int warmup, int reps, double *ms_per_launch);
+/* Same for one full FGMRES-cycle kernel sequence is done by spk_fgmres itself
+ * (spk_result.solve_seconds). */
+
+/* ---- host-only helpers: row-slab partition and halo plan ------------------ */
+/* (callable without a GPU; used by the multi-rank CPU tests) */
+/* Rows owned by `rank` of `nranks` when `nlines` grid lines of `line_rows`
+ * rows each are dealt in contiguous slabs (PETSc's default DMDA split in y). */
+int spk_partition_slab(int64_t nlines, int64_t line_rows, int rank, int nranks,
+                       int64_t *row_begin, int64_t *row_end);
+/* Splits a local CSR slab with global columns into the diagonal block (local
+ * column numbers) and the off-diagonal block (ghost numbers 0..n_ghost-1,
+ * ghosts sorted by global column) -- MatMPIAIJ's (Ad, Ao, garray).
+ * Call once with the output arrays NULL to get the sizes. */
+int spk_partition_split(int64_t row_begin, int32_t nrows_local, const int32_t *rowptr,
+                        const int32_t *colidx, const double *val,
+                        int32_t *d_rowptr, int32_t *d_colidx, double *d_val,
+                        int32_t *o_rowptr, int32_t *o_colidx, double *o_val,
+                        int32_t *garray, int64_t *nnz_d, int64_t *nnz_o, int32_t *n_ghost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPK_H */

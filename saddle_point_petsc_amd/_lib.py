@@ -1,0 +1,116 @@
+"""ctypes binding of libspk.so (include/spk.h, spk_ksp.h, spk_assembly.h).
+
+The library is built in-tree by `make -C saddle_point_petsc_amd/csrc` (or
+`__graft_entry__.build()`).  There is NO fallback: if libspk.so is missing the
+import fails, and without a GPU `spk_create` fails -- nothing here computes on
+the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspk.so")
+
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class SpkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libspk error {code}: {msg}")
+        self.code = code
+
+
+class Opts(C.Structure):
+    _fields_ = [
+        ("restart", C.c_int32), ("max_it", C.c_int32), ("rtol", C.c_double),
+        ("abstol", C.c_double), ("dtol", C.c_double), ("guess_nonzero", C.c_int32),
+        ("orthog", C.c_int32), ("check_every", C.c_int32), ("fused", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("its", C.c_int32), ("reason", C.c_int32), ("rnorm", C.c_double),
+        ("rnorm0", C.c_double), ("hist_len", C.c_int32), ("cycles", C.c_int32),
+        ("solve_seconds", C.c_double),
+    ]
+
+
+class MatCSR(C.Structure):
+    _fields_ = [
+        ("row_begin", C.c_int64), ("nrows_local", C.c_int32), ("pad", C.c_int32),
+        ("ncols_global", C.c_int64), ("rowptr", C.c_void_p), ("colidx", C.c_void_p),
+        ("val", C.c_void_p),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(hipcc, gfx950).  saddle_point_petsc_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.spk_version.restype = C.c_int
+    L.spk_last_error.restype = C.c_char_p
+    L.spk_last_error.argtypes = [vp]
+    L.spk_default_opts.argtypes = [C.POINTER(Opts)]
+    L.spk_default_opts.restype = None
+    L.spk_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.spk_destroy.argtypes = [vp]
+    L.spk_comm_unique_id.argtypes = [C.c_char_p]
+    L.spk_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.spk_local_group_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.spk_local_group_destroy.argtypes = [vp]
+    L.spk_comm_init_local.argtypes = [vp, vp, C.c_int]
+    L.spk_set_block.argtypes = [vp, C.c_int, i64, i32, i64, i32p, i32p, f64p]
+    L.spk_pc_setup.argtypes = [vp, C.c_int, C.c_int]
+    L.spk_get_schur_diag.argtypes = [vp, f64p]
+    L.spk_get_jacobi_diag.argtypes = [vp, f64p]
+    L.spk_mult.argtypes = [vp, f64p, f64p, C.c_int]
+    L.spk_pc_apply.argtypes = [vp, f64p, f64p, C.c_int]
+    L.spk_fgmres.argtypes = [vp, f64p, f64p, C.c_int, C.POINTER(Opts), C.POINTER(Result), vp, i32]
+    L.spk_get_sizes.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
+    L.spk_kernel_mdot.argtypes = [vp, i64, i32, f64p, i64, f64p, f64p]
+    L.spk_kernel_maxpy.argtypes = [vp, i64, i32, f64p, f64p, i64, f64p, C.POINTER(dbl)]
+    L.spk_time_spmv.argtypes = [vp, C.c_int, C.c_int, C.POINTER(dbl)]
+    L.spk_partition_slab.argtypes = [i64, i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.spk_partition_split.argtypes = [i64, i32, i32p, i32p, f64p] + [vp] * 7 + [C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
+    # assembly
+    L.SpkAssemblySizes.argtypes = [C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.SpkAssemblySlabNnz.restype = i64
+    L.SpkAssemblySlabNnz.argtypes = [C.c_int, C.c_int, i64, i64]
+    L.SpkAssembleOperator_Laplace.argtypes = [C.c_int, C.c_int, i64, i64, i32p, i32p, f64p, vp, C.c_int, C.c_int]
+    L.SpkConstraintsSlabNnz.restype = i64
+    L.SpkConstraintsSlabNnz.argtypes = [C.c_int, C.c_int, i64, i64]
+    L.SpkAssembleOperator_Constraints.argtypes = [C.c_int, C.c_int, i64, i64, i32p, i32p, f64p]
+    L.SpkAssembleRHS_Constraints.argtypes = [f64p]
+    L.SpkFormStressOperatorQ12D.argtypes = [f64p, f64p, f64p]
+    L.SpkFormLaplaceRHSQ12D.argtypes = [f64p, f64p]
+    # KSP facade
+    L.SpkKSPCreate.argtypes = [C.c_int, C.POINTER(vp)]
+    L.SpkKSPSetCommRCCL.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.SpkKSPSetOperators.argtypes = [vp, C.POINTER(MatCSR), C.POINTER(MatCSR)]
+    L.SpkKSPSetFromOptions.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p)]
+    L.SpkKSPSetUp.argtypes = [vp]
+    L.SpkKSPSolve.argtypes = [vp, f64p, f64p]
+    L.SpkKSPDestroy.argtypes = [C.POINTER(vp)]
+    L.SpkKSPGetIterationNumber.argtypes = [vp, C.POINTER(i32)]
+    L.SpkKSPGetConvergedReason.argtypes = [vp, C.POINTER(i32)]
+    L.SpkKSPGetResidualNorm.argtypes = [vp, C.POINTER(dbl)]
+    L.SpkKSPGetResidualHistory.argtypes = [vp, C.POINTER(C.POINTER(dbl)), C.POINTER(i32)]
+    L.SpkKSPGetSolveTime.argtypes = [vp, C.POINTER(dbl)]
+    L.SpkKSPGetOptions.argtypes = [vp, C.POINTER(Opts), C.POINTER(i32), C.POINTER(i32)]
+    L.SpkKSPGetContext.argtypes = [vp, C.POINTER(vp)]
+    L.SpkKSPGetError.restype = C.c_char_p
+    L.SpkKSPGetError.argtypes = [vp]
+    L.SpkKSPConvergedReasonName.restype = C.c_char_p
+    L.SpkKSPConvergedReasonName.argtypes = [i32]
+    return L
+
+
+lib = _load()

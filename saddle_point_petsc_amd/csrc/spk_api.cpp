@@ -1,0 +1,314 @@
+// spk_api.cpp -- the extern "C" surface declared in include/spk.h.
+// Argument checks, error capture (exceptions never cross the ABI), staging of
+// host vectors.  The work is in spk_solver.cpp / spk_kernels.hip.
+#include <cmath>
+#include <cstring>
+
+#include "spk_internal.hpp"
+
+namespace spk {
+void rccl_unique_id(void *id128);
+}
+
+static thread_local std::string g_create_error;
+
+#define SPK_TRY(ctx)                                                     \
+    if (!(ctx)) return SPK_ERR_ARG;                                      \
+    try {                                                                \
+        if (hipSetDevice((ctx)->device) != hipSuccess)                   \
+            spk::fail(SPK_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device);
+
+#define SPK_CATCH(ctx)                                                   \
+    }                                                                    \
+    catch (const spk::Error &e)                                          \
+    {                                                                    \
+        (ctx)->err = e.msg;                                              \
+        return e.code;                                                   \
+    }                                                                    \
+    catch (const std::exception &e)                                      \
+    {                                                                    \
+        (ctx)->err = e.what();                                           \
+        return SPK_ERR_NOMEM;                                            \
+    }                                                                    \
+    return SPK_OK;
+
+extern "C" {
+
+int spk_version(void) { return SPK_VERSION; }
+
+void spk_default_opts(spk_opts *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->restart = 30;
+    o->max_it = 10000;
+    o->rtol = 1e-5;
+    o->abstol = 1e-50;
+    o->dtol = 1e4;
+    o->guess_nonzero = 0;
+    o->orthog = SPK_ORTHOG_CGS;
+    o->check_every = 0;
+    o->fused = 0;
+}
+
+int spk_create(spk_ctx **out, int device)
+{
+    if (!out) return SPK_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("spk_create: no HIP device available (") + hipGetErrorString(e) +
+                         "); libspk has no CPU fallback";
+        return SPK_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "spk_create: device index out of range";
+        return SPK_ERR_ARG;
+    }
+    spk_ctx *c = nullptr;
+    try {
+        c = new spk_ctx();
+        c->device = device;
+        SPK_HIP(hipSetDevice(device));
+        SPK_HIP(hipStreamCreate(&c->stream));
+        c->comm.reset(spk::make_self_comm());
+        c->ensure_scratch();
+    } catch (const spk::Error &er) {
+        g_create_error = er.msg;
+        delete c;
+        return er.code;
+    } catch (const std::exception &er) {
+        g_create_error = er.what();
+        delete c;
+        return SPK_ERR_NOMEM;
+    }
+    *out = c;
+    return SPK_OK;
+}
+
+int spk_destroy(spk_ctx *c)
+{
+    if (!c) return SPK_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    c->comm.reset();
+    hipStream_t s = c->stream;
+    delete c;  // DevBuf destructors free device memory
+    if (s) (void)hipStreamDestroy(s);
+    return SPK_OK;
+}
+
+const char *spk_last_error(const spk_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int spk_comm_unique_id(void *id128)
+{
+    if (!id128) return SPK_ERR_ARG;
+    try {
+        spk::rccl_unique_id(id128);
+    } catch (const spk::Error &e) {
+        g_create_error = e.msg;
+        return e.code;
+    }
+    return SPK_OK;
+}
+
+int spk_comm_init_rccl(spk_ctx *c, int rank, int nranks, const void *id128)
+{
+    SPK_TRY(c)
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) spk::fail(SPK_ERR_ARG, "comm_init_rccl: bad rank/nranks");
+    if (c->have_A) spk::fail(SPK_ERR_STATE, "comm_init: must precede spk_set_block");
+    c->comm.reset(spk::make_rccl_comm(rank, nranks, id128, c->device));
+    SPK_CATCH(c)
+}
+
+int spk_comm_init_local(spk_ctx *c, spk_local_group *grp, int rank)
+{
+    SPK_TRY(c)
+    if (!grp) spk::fail(SPK_ERR_ARG, "comm_init_local: null group");
+    if (c->have_A) spk::fail(SPK_ERR_STATE, "comm_init: must precede spk_set_block");
+    c->comm.reset(spk::make_local_comm(grp, rank));
+    SPK_CATCH(c)
+}
+
+int spk_set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
+                  const int32_t *rowptr, const int32_t *colidx, const double *val)
+{
+    SPK_TRY(c)
+    spk::set_block(c, which, row_begin, nrows_local, ncols_global, rowptr, colidx, val);
+    SPK_CATCH(c)
+}
+
+int spk_pc_setup(spk_ctx *c, int pc_type, int schur_fact)
+{
+    SPK_TRY(c)
+    spk::pc_setup(c, pc_type, schur_fact);
+    SPK_CATCH(c)
+}
+
+int spk_get_schur_diag(spk_ctx *c, double *shat)
+{
+    SPK_TRY(c)
+    if (!shat) spk::fail(SPK_ERR_ARG, "null output");
+    if (!c->pc_ready || c->m == 0 || !c->shat.p) spk::fail(SPK_ERR_STATE, "no Schur data: call spk_pc_setup with the A10 block set");
+    SPK_HIP(hipMemcpy(shat, c->shat.p, sizeof(double) * (size_t)c->m, hipMemcpyDeviceToHost));
+    SPK_CATCH(c)
+}
+
+int spk_get_jacobi_diag(spk_ctx *c, double *dinv)
+{
+    SPK_TRY(c)
+    if (!dinv) spk::fail(SPK_ERR_ARG, "null output");
+    if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "call spk_pc_setup first");
+    SPK_HIP(hipMemcpy(dinv, c->dinv.p, sizeof(double) * (size_t)c->n_local, hipMemcpyDeviceToHost));
+    SPK_CATCH(c)
+}
+
+int spk_get_sizes(const spk_ctx *c, int64_t *n_global, int32_t *n_local, int32_t *m, int64_t *nnz_local,
+                  int32_t *n_ghost)
+{
+    if (!c) return SPK_ERR_ARG;
+    if (n_global) *n_global = c->n_global;
+    if (n_local) *n_local = c->n_local;
+    if (m) *m = c->m;
+    if (nnz_local) *nnz_local = c->Ad.nnz + c->Ao.nnz;
+    if (n_ghost) *n_ghost = c->n_ghost;
+    return SPK_OK;
+}
+
+// stage a host vector into a zero-padded device buffer / pass a device pointer through
+static const double *stage_in(spk_ctx *c, const double *p, int mem, spk::DevBuf<double> &buf, int64_t n)
+{
+    if (mem == SPK_MEM_DEVICE) return p;
+    SPK_HIP(hipMemcpyAsync(buf.p, p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    return buf.p;
+}
+
+int spk_mult(spk_ctx *c, const double *x, double *y, int mem)
+{
+    SPK_TRY(c)
+    if (!x || !y) spk::fail(SPK_ERR_ARG, "spk_mult: null vector");
+    if (!c->have_A) spk::fail(SPK_ERR_STATE, "spk_mult: no operator");
+    c->ensure_vectors();
+    const int64_t N = (int64_t)c->n_local + c->m;
+    const double *xd = stage_in(c, x, mem, c->stage_x, N);
+    double *yd = mem == SPK_MEM_DEVICE ? y : c->stage_y.p;
+    spk::op_mult(c, xd, yd, nullptr);
+    if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    SPK_CATCH(c)
+}
+
+int spk_pc_apply(spk_ctx *c, const double *x, double *y, int mem)
+{
+    SPK_TRY(c)
+    if (!x || !y) spk::fail(SPK_ERR_ARG, "spk_pc_apply: null vector");
+    if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "spk_pc_apply: call spk_pc_setup first");
+    const int64_t N = (int64_t)c->n_local + c->m;
+    const double *xd = stage_in(c, x, mem, c->stage_x, N);
+    double *yd = mem == SPK_MEM_DEVICE ? y : c->stage_y.p;
+    spk::op_pc_apply(c, xd, yd, nullptr);
+    if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    SPK_CATCH(c)
+}
+
+int spk_fgmres(spk_ctx *c, const double *b, double *x, int mem, const spk_opts *opts, spk_result *result,
+               double *history, int32_t history_cap)
+{
+    SPK_TRY(c)
+    if (!b || !x || !opts || !result) spk::fail(SPK_ERR_ARG, "spk_fgmres: null argument");
+    if (!c->have_A) spk::fail(SPK_ERR_STATE, "spk_fgmres: no operator");
+    if (!(opts->rtol >= 0) || !(opts->abstol >= 0) || !(opts->dtol > 0) || opts->max_it < 0)
+        spk::fail(SPK_ERR_ARG, "spk_fgmres: tolerances must be non-negative, max_it >= 0");
+    c->ensure_vectors();
+    const int64_t N = (int64_t)c->n_local + c->m;
+    std::memset(result, 0, sizeof *result);
+    if (mem == SPK_MEM_DEVICE) {
+        spk::fgmres(c, b, x, *opts, result, history, history_cap);
+    } else {
+        spk_opts o = *opts;
+        double *xs = c->xsol.p, *rh = c->rhs.p;
+        SPK_HIP(hipMemcpy(rh, b, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+        if (o.guess_nonzero) SPK_HIP(hipMemcpy(xs, x, sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+        spk::fgmres(c, rh, xs, o, result, history, history_cap);
+        SPK_HIP(hipMemcpy(x, xs, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
+    }
+    SPK_CATCH(c)
+}
+
+// ---- single kernels through the ABI -----------------------------------------
+int spk_kernel_mdot(spk_ctx *c, int64_t n, int32_t nv, const double *V, int64_t ldv, const double *w, double *h)
+{
+    SPK_TRY(c)
+    if (!V || !w || !h || n <= 0 || nv < 0 || nv > spk::k::kMaxNv - 1 || ldv < n)
+        spk::fail(SPK_ERR_ARG, "spk_kernel_mdot: bad arguments");
+    c->ensure_scratch();
+    const int64_t ld = (n + 255) / 256 * 256;
+    spk::DevBuf<double> dV, dw;
+    dV.alloc((size_t)ld * (size_t)std::max(nv, 1));
+    dw.alloc((size_t)ld);
+    for (int i = 0; i < nv; ++i)
+        SPK_HIP(hipMemcpy(dV.p + (size_t)ld * i, V + (size_t)ldv * i, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    SPK_HIP(hipMemcpy(dw.p, w, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    int nb = 0;
+    spk::k::mdot(dV.p, ld, nv, dw.p, n, n, c->partials.p, &nb, nullptr, c->stream);
+    spk::k::reduce_partials(c->partials.p, nb, spk::k::kPartialLd, nv + 1, c->small.p, nullptr, c->stream);
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    SPK_HIP(hipMemcpy(h, c->small.p, sizeof(double) * (size_t)(nv + 1), hipMemcpyDeviceToHost));
+    SPK_CATCH(c)
+}
+
+int spk_kernel_maxpy(spk_ctx *c, int64_t n, int32_t nv, const double *a, const double *V, int64_t ldv,
+                     double *w, double *nrm2)
+{
+    SPK_TRY(c)
+    if (!V || !w || !a || n <= 0 || nv < 0 || nv > spk::k::kMaxNv - 1 || ldv < n)
+        spk::fail(SPK_ERR_ARG, "spk_kernel_maxpy: bad arguments");
+    c->ensure_scratch();
+    const int64_t ld = (n + 255) / 256 * 256;
+    spk::DevBuf<double> dV, dw, da;
+    dV.alloc((size_t)ld * (size_t)std::max(nv, 1));
+    dw.alloc((size_t)ld);
+    da.upload(a, (size_t)nv, 8);
+    for (int i = 0; i < nv; ++i)
+        SPK_HIP(hipMemcpy(dV.p + (size_t)ld * i, V + (size_t)ldv * i, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    SPK_HIP(hipMemcpy(dw.p, w, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    int nb = 0;
+    spk::k::maxpy(dV.p, ld, nv, nullptr, da.p, 1.0, dw.p, n, n, c->partials.p, &nb, nullptr, c->stream);
+    spk::k::reduce_partials(c->partials.p, nb, spk::k::kPartialLd, 1, c->small.p, nullptr, c->stream);
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    SPK_HIP(hipMemcpy(w, dw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    if (nrm2) SPK_HIP(hipMemcpy(nrm2, c->small.p, sizeof(double), hipMemcpyDeviceToHost));
+    SPK_CATCH(c)
+}
+
+int spk_time_spmv(spk_ctx *c, int warmup, int reps, double *ms_per_launch)
+{
+    SPK_TRY(c)
+    if (!ms_per_launch || reps < 1 || warmup < 0) spk::fail(SPK_ERR_ARG, "spk_time_spmv: bad arguments");
+    if (!c->have_A) spk::fail(SPK_ERR_STATE, "spk_time_spmv: no operator");
+    c->ensure_vectors();
+    const int64_t N = (int64_t)c->n_local + c->m;
+    std::vector<double> hx((size_t)N);
+    for (int64_t i = 0; i < N; ++i) hx[(size_t)i] = std::sin(0.37 * (double)(c->row_begin + i));
+    SPK_HIP(hipMemcpy(c->stage_x.p, hx.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    SPK_HIP(hipEventCreate(&e0));
+    SPK_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) spk::k::spmv(c->Ad, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
+    SPK_HIP(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i) spk::k::spmv(c->Ad, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
+    SPK_HIP(hipEventRecord(e1, c->stream));
+    SPK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / reps;
+    SPK_CATCH(c)
+}
+
+}  // extern "C"

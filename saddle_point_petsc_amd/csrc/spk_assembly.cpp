@@ -1,0 +1,314 @@
+// spk_assembly.cpp -- threaded, PETSc-free assembler (see include/spk_assembly.h).
+//
+// Not the reference's scatter loop: rows are GATHERED.  A thread owns a run of
+// node lines, computes the element matrices of the two adjacent element lines
+// once, and writes each CSR row directly from the <= 4 elements around its
+// node, visiting them in ascending (ej, ei) -- the order in which the
+// reference's element loop (Discretization.c:146-147) would have added them --
+// so every stored value is bit-identical to a sequential ADD_VALUES assembly
+// while no two threads ever touch the same entry.
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/spk_assembly.h"
+#include "../../include/spk.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// 2x2 Gauss points; the 11-digit abscissa is the reference's (Discretization.c:52-55)
+const double kGp[4][2] = {{-0.57735026919, -0.57735026919},
+                          {-0.57735026919, 0.57735026919},
+                          {0.57735026919, 0.57735026919},
+                          {0.57735026919, -0.57735026919}};
+
+struct GaussPoint {
+    double N[4];      // shape functions
+    double dN[2][4];  // reference gradients
+};
+
+GaussPoint make_gp(int p)
+{
+    GaussPoint g;
+    const double xi = kGp[p][0], eta = kGp[p][1];
+    g.N[0] = 0.25 * (1.0 - xi) * (1.0 - eta);
+    g.N[1] = 0.25 * (1.0 - xi) * (1.0 + eta);
+    g.N[2] = 0.25 * (1.0 + xi) * (1.0 + eta);
+    g.N[3] = 0.25 * (1.0 + xi) * (1.0 - eta);
+    g.dN[0][0] = -0.25 * (1.0 - eta);
+    g.dN[0][1] = -0.25 * (1.0 + eta);
+    g.dN[0][2] = 0.25 * (1.0 + eta);
+    g.dN[0][3] = 0.25 * (1.0 - eta);
+    g.dN[1][0] = -0.25 * (1.0 - xi);
+    g.dN[1][1] = 0.25 * (1.0 - xi);
+    g.dN[1][2] = 0.25 * (1.0 + xi);
+    g.dN[1][3] = -0.25 * (1.0 + xi);
+    return g;
+}
+
+// physical gradients at one Gauss point; returns det J
+double phys_grad(const GaussPoint &g, const double *xe, double gx[2][4])
+{
+    double J[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int c = 0; c < 2; ++c)
+        for (int d = 0; d < 2; ++d)
+            for (int i = 0; i < 4; ++i) J[c][d] += g.dN[c][i] * xe[2 * i + d];
+    const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double i00 = J[1][1] / det, i01 = -J[0][1] / det, i10 = -J[1][0] / det, i11 = J[0][0] / det;
+    for (int i = 0; i < 4; ++i) {
+        gx[0][i] = i00 * g.dN[0][i] + i01 * g.dN[1][i];
+        gx[1][i] = i10 * g.dN[0][i] + i11 * g.dN[1][i];
+    }
+    return det;
+}
+
+// Ke[a*8+b]; strain-displacement rows (exx, eyy, 2exy), D = diag(2,2,1)
+void stiffness(const double *xe, const double *coeff, double *Ke)
+{
+    double acc[64];  // acc[i + 8 j], the reference's index (symmetric anyway)
+    std::memset(acc, 0, sizeof acc);
+    for (int p = 0; p < 4; ++p) {
+        const GaussPoint g = make_gp(p);
+        double gx[2][4], Bm[3][8], tD[3];
+        const double det = phys_grad(g, xe, gx);
+        for (int i = 0; i < 4; ++i) {
+            Bm[0][2 * i] = gx[0][i]; Bm[0][2 * i + 1] = 0.0;
+            Bm[1][2 * i] = 0.0;      Bm[1][2 * i + 1] = gx[1][i];
+            Bm[2][2 * i] = gx[1][i]; Bm[2][2 * i + 1] = gx[0][i];
+        }
+        tD[0] = 2.0 * 1.0 * det * coeff[p];
+        tD[1] = 2.0 * 1.0 * det * coeff[p];
+        tD[2] = 1.0 * det * coeff[p];
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j)
+                for (int k = 0; k < 3; ++k) acc[i + 8 * j] += Bm[k][i] * tD[k] * Bm[k][j];
+    }
+    // the reference hands Ae to MatSetValuesStencil row-major: (row a, col b) = Ae[a*8+b]
+    std::memcpy(Ke, acc, sizeof acc);
+}
+
+void load(const double *xe, double *Fe)
+{
+    std::memset(Fe, 0, 8 * sizeof(double));
+    for (int p = 0; p < 4; ++p) {
+        const GaussPoint g = make_gp(p);
+        double gx[2][4];
+        const double fac = 1.0 * phys_grad(g, xe, gx);
+        const double body[2] = {1.0, 2.0};  // FormRHS, Discretization.c:397-402
+        for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 2; ++c) Fe[2 * i + c] += fac * g.N[i] * body[c];
+    }
+}
+
+inline double coord(int i, int m) { return 0.0 + (1.0 / (double)(m - 1)) * (double)i; }
+
+void element_coords(int mx, int my, int ei, int ej, double *xe)
+{
+    xe[0] = coord(ei, mx);     xe[1] = coord(ej, my);
+    xe[2] = coord(ei, mx);     xe[3] = coord(ej + 1, my);
+    xe[4] = coord(ei + 1, mx); xe[5] = coord(ej + 1, my);
+    xe[6] = coord(ei + 1, mx); xe[7] = coord(ej, my);
+}
+
+// local node number of the corner at offset (oi, oj) from the element origin
+inline int corner(int oi, int oj) { return oi == 0 ? (oj == 0 ? 0 : 1) : (oj == 0 ? 3 : 2); }
+
+inline bool on_boundary(int mx, int my, int i, int j) { return i == 0 || i == mx - 1 || j == 0 || j == my - 1; }
+
+// stored non-zeros of the two rows of node (i,j)
+inline int node_row_nnz(int mx, int my, int i, int j)
+{
+    const int wi = (i > 0) + 1 + (i < mx - 1), wj = (j > 0) + 1 + (j < my - 1);
+    return wi * wj * 2;
+}
+
+int threads_or_default(int n)
+{
+    if (n > 0) return n;
+    const unsigned h = std::thread::hardware_concurrency();
+    return h ? (int)h : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int SpkAssemblySizes(int mx, int my, int64_t *nrows, int64_t *nnz)
+{
+    if (mx < 2 || my < 2) return SPK_ERR_ARG;
+    if (nrows) *nrows = (int64_t)2 * mx * my;
+    if (nnz) *nnz = (int64_t)4 * (3 * (int64_t)mx - 2) * (3 * (int64_t)my - 2);
+    return SPK_OK;
+}
+
+int64_t SpkAssemblySlabNnz(int mx, int my, int64_t row_begin, int64_t row_end)
+{
+    const int64_t line = (int64_t)2 * mx;
+    if (mx < 2 || my < 2 || row_begin % line || row_end % line || row_begin > row_end || row_end > line * my) return -1;
+    int64_t nnz = 0;
+    for (int64_t j = row_begin / line; j < row_end / line; ++j) {
+        const int64_t wj = (j > 0) + 1 + (j < my - 1);
+        nnz += 4 * wj * (3 * (int64_t)mx - 2);
+    }
+    return nnz;
+}
+
+int SpkAssembleOperator_Laplace(int mx, int my, int64_t row_begin, int64_t row_end, int32_t *rowptr,
+                                int32_t *colidx, double *val, double *f, int apply_bc, int nthreads)
+{
+    const int64_t line = (int64_t)2 * mx;
+    if (!rowptr || !colidx || !val) return SPK_ERR_ARG;
+    if (SpkAssemblySlabNnz(mx, my, row_begin, row_end) < 0) return SPK_ERR_ARG;
+    if ((int64_t)2 * mx * my > INT32_MAX) return SPK_ERR_UNSUPPORTED;
+    const int j0 = (int)(row_begin / line), j1 = (int)(row_end / line);
+
+    // row pointers (closed form per node)
+    {
+        int64_t k = 0;
+        int64_t r = 0;
+        for (int j = j0; j < j1; ++j)
+            for (int i = 0; i < mx; ++i) {
+                const int w = node_row_nnz(mx, my, i, j);
+                rowptr[r++] = (int32_t)k; k += w;
+                rowptr[r++] = (int32_t)k; k += w;
+            }
+        rowptr[r] = (int32_t)k;
+        if (k > INT32_MAX) return SPK_ERR_UNSUPPORTED;
+    }
+
+    const int nt = std::max(1, std::min(threads_or_default(nthreads), j1 - j0));
+    auto work = [&](int t) {
+        const int ja = j0 + (int)((int64_t)(j1 - j0) * t / nt), jb = j0 + (int)((int64_t)(j1 - j0) * (t + 1) / nt);
+        const int ne = mx - 1;
+        // element matrices / loads of element lines below (ej = j-1) and above (ej = j)
+        std::vector<double> KeLo((size_t)ne * 64), KeHi((size_t)ne * 64), FeLo((size_t)ne * 8), FeHi((size_t)ne * 8);
+        const double coeff[4] = {1.0, 1.0, 1.0, 1.0};
+        auto fill_line = [&](int ej, std::vector<double> &Ke, std::vector<double> &Fe) {
+            if (ej < 0 || ej > my - 2) return;
+            for (int ei = 0; ei < ne; ++ei) {
+                double xe[8];
+                element_coords(mx, my, ei, ej, xe);
+                stiffness(xe, coeff, &Ke[(size_t)ei * 64]);
+                load(xe, &Fe[(size_t)ei * 8]);
+            }
+        };
+        fill_line(ja - 1, KeLo, FeLo);
+        for (int j = ja; j < jb; ++j) {
+            fill_line(j, KeHi, FeHi);
+            for (int i = 0; i < mx; ++i) {
+                const bool rb = on_boundary(mx, my, i, j);
+                for (int c = 0; c < 2; ++c) {
+                    const int64_t grow = ((int64_t)j * mx + i) * 2 + c;
+                    const int64_t lrow = grow - row_begin;
+                    int64_t k = rowptr[lrow];
+                    for (int dj = -1; dj <= 1; ++dj) {
+                        const int cj = j + dj;
+                        if (cj < 0 || cj >= my) continue;
+                        for (int di = -1; di <= 1; ++di) {
+                            const int ci = i + di;
+                            if (ci < 0 || ci >= mx) continue;
+                            const bool cb = on_boundary(mx, my, ci, cj);
+                            for (int d = 0; d < 2; ++d) {
+                                const int64_t gcol = ((int64_t)cj * mx + ci) * 2 + d;
+                                double v = 0.0;
+                                // elements that hold both nodes, ascending (ej, ei)
+                                for (int ej = std::max(j, cj) - 1; ej <= std::min(j, cj); ++ej) {
+                                    if (ej < 0 || ej > my - 2) continue;
+                                    const std::vector<double> &Ke = (ej == j - 1) ? KeLo : KeHi;
+                                    for (int ei = std::max(i, ci) - 1; ei <= std::min(i, ci); ++ei) {
+                                        if (ei < 0 || ei > mx - 2) continue;
+                                        const int a = corner(i - ei, j - ej) * 2 + c;
+                                        const int b = corner(ci - ei, cj - ej) * 2 + d;
+                                        v += Ke[(size_t)ei * 64 + a * 8 + b];
+                                    }
+                                }
+                                if (apply_bc && (rb || cb)) v = (gcol == grow) ? 1.0 : 0.0;
+                                colidx[k] = (int32_t)gcol;
+                                val[k] = v;
+                                ++k;
+                            }
+                        }
+                    }
+                    if (f) {
+                        double fv = 0.0;
+                        for (int ej = j - 1; ej <= j; ++ej) {
+                            if (ej < 0 || ej > my - 2) continue;
+                            const std::vector<double> &Fe = (ej == j - 1) ? FeLo : FeHi;
+                            for (int ei = i - 1; ei <= i; ++ei) {
+                                if (ei < 0 || ei > mx - 2) continue;
+                                fv += Fe[(size_t)ei * 8 + corner(i - ei, j - ej) * 2 + c];
+                            }
+                        }
+                        f[lrow] = (apply_bc && rb) ? 0.0 : fv;
+                    }
+                }
+            }
+            std::swap(KeLo, KeHi);
+            std::swap(FeLo, FeHi);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    return SPK_OK;
+}
+
+int64_t SpkConstraintsSlabNnz(int mx, int my, int64_t row_begin, int64_t row_end)
+{
+    const int64_t line = (int64_t)2 * mx;
+    if (mx < 3 || my < 3 || row_begin % line || row_end % line || row_begin > row_end || row_end > line * my) return -1;
+    int64_t lines = 0;
+    for (int64_t j = row_begin / line; j < row_end / line; ++j) lines += (j > 0 && j < my - 1);
+    return 4 * lines * (mx - 2);
+}
+
+int SpkAssembleOperator_Constraints(int mx, int my, int64_t row_begin, int64_t row_end, int32_t *rowptr,
+                                    int32_t *colidx, double *val)
+{
+    if (!rowptr || !colidx || !val || SpkConstraintsSlabNnz(mx, my, row_begin, row_end) < 0) return SPK_ERR_ARG;
+    const int64_t line = (int64_t)2 * mx;
+    const int j0 = (int)(row_begin / line), j1 = (int)(row_end / line);
+    const double hx = 1.0 / (double)(mx - 1), hy = 1.0 / (double)(my - 1), w = hx * hy;
+    int64_t k = 0;
+    for (int r = 0; r < 4; ++r) {
+        rowptr[r] = (int32_t)k;
+        for (int j = std::max(j0, 1); j < std::min(j1, my - 1); ++j)
+            for (int i = 1; i < mx - 1; ++i) {
+                double v = w;
+                if (r == 2) v = w * (coord(i, mx) - 0.5);
+                if (r == 3) v = w * (coord(j, my) - 0.5);
+                colidx[k] = (int32_t)(((int64_t)j * mx + i) * 2 + (r & 1));
+                val[k] = v;
+                ++k;
+            }
+    }
+    rowptr[4] = (int32_t)k;
+    return SPK_OK;
+}
+
+int SpkAssembleRHS_Constraints(double *g)
+{
+    if (!g) return SPK_ERR_ARG;
+    g[0] = 1e-2; g[1] = -2e-2; g[2] = 3e-3; g[3] = 1e-3;
+    return SPK_OK;
+}
+
+int SpkFormStressOperatorQ12D(const double *xe, const double *coeff4, double *Ke64)
+{
+    if (!xe || !coeff4 || !Ke64) return SPK_ERR_ARG;
+    stiffness(xe, coeff4, Ke64);
+    return SPK_OK;
+}
+
+int SpkFormLaplaceRHSQ12D(const double *xe, double *Fe8)
+{
+    if (!xe || !Fe8) return SPK_ERR_ARG;
+    load(xe, Fe8);
+    return SPK_OK;
+}
+
+}  // extern "C"

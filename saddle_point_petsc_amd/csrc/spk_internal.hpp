@@ -1,0 +1,277 @@
+// spk_internal.hpp -- private declarations shared by the libspk.so sources.
+//
+// Layering (MI355X-first, not PETSc's):
+//   spk_api.cpp      C ABI entry points, argument checks, error strings
+//   spk_solver.cpp   device-resident FGMRES: the host only ENQUEUES a restart
+//                    cycle; Hessenberg/Givens/convergence live on the device
+//   spk_kernels.hip  hand-written gfx950 kernels (HBM-bound, FP64, no MFMA)
+//   spk_comm.cpp     collectives: self / RCCL (one process per GPU) / local
+//   spk_partition.cpp host-only row-slab split + halo plan
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/spk.h"
+
+namespace spk {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+struct Error {
+    int code;
+    std::string msg;
+};
+[[noreturn]] void fail(int code, const char *fmt, ...);
+
+#define SPK_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            ::spk::fail(SPK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// device memory
+// ---------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    // allocates `count` (+pad) elements, zero-filled
+    void alloc(size_t count, size_t pad = 0)
+    {
+        release();
+        n = count;
+        size_t bytes = (count + pad) * sizeof(T);
+        if (bytes == 0) bytes = sizeof(T);
+        SPK_HIP(hipMalloc((void **)&p, bytes));
+        SPK_HIP(hipMemset(p, 0, bytes));
+    }
+    void upload(const T *h, size_t count, size_t pad = 0)
+    {
+        alloc(count, pad);
+        if (count) SPK_HIP(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+// CSR block on the device, prepared for the row-tiled stream kernel.
+struct CsrDev {
+    int32_t nrows = 0, ncols = 0;
+    int64_t nnz = 0;
+    DevBuf<int32_t> rowptr, colidx;
+    DevBuf<double> val;
+    // stream tiling: tile t covers rows [tile_row[t], tile_row[t+1])
+    DevBuf<int32_t> tile_row;
+    int32_t ntiles = 0;
+};
+
+// Short-and-wide block (B: m rows x n_local cols) cut into column windows so
+// that x is streamed once for all m rows.
+struct WideDev {
+    int32_t m = 0, ncols = 0, nwin = 0, win = 0;
+    int64_t nnz = 0;
+    DevBuf<int32_t> colidx;  // nnz, rows concatenated, ascending in a row
+    DevBuf<double> val;
+    DevBuf<int32_t> winptr;  // (nwin+1) x m : start of window w in row r
+};
+
+// ---------------------------------------------------------------------------
+// collectives
+// ---------------------------------------------------------------------------
+struct HaloPlan;
+class Comm {
+public:
+    virtual ~Comm() {}
+    virtual int rank() const { return 0; }
+    virtual int size() const { return 1; }
+    // in-place sum over ranks of `count` doubles in device memory, stream-ordered
+    virtual void allreduce_sum(double *dev, int count, hipStream_t s) { (void)dev; (void)count; (void)s; }
+    // exchange of packed halo segments: sendbuf[send_off[p]..] -> peer p,
+    // peer p's segment lands in recvbuf[recv_off[p]..]
+    virtual void exchange(const double *sendbuf, const std::vector<int> &peers,
+                          const std::vector<int64_t> &send_off, double *recvbuf,
+                          const std::vector<int64_t> &recv_off, hipStream_t s)
+    { (void)sendbuf; (void)peers; (void)send_off; (void)recvbuf; (void)recv_off; (void)s; }
+    // host-side exchange of small setup data (sizes, index lists)
+    virtual void host_allgather(const void *in, void *out, size_t bytes_each) { memcpy_self(in, out, bytes_each); }
+    virtual void host_allgatherv(const void *in, size_t bytes_in, std::vector<std::vector<char>> &out)
+    {
+        out.assign(1, std::vector<char>((const char *)in, (const char *)in + bytes_in));
+    }
+protected:
+    static void memcpy_self(const void *in, void *out, size_t b);
+};
+Comm *make_self_comm();
+Comm *make_rccl_comm(int rank, int nranks, const void *id128, int device);
+Comm *make_local_comm(spk_local_group *grp, int rank);
+
+// ---------------------------------------------------------------------------
+// host-side partition results
+// ---------------------------------------------------------------------------
+struct SplitCsr {
+    std::vector<int32_t> d_rowptr, d_colidx, o_rowptr, o_colidx, garray;
+    std::vector<double> d_val, o_val;
+};
+void split_csr(int64_t row_begin, int32_t nrows_local, const int32_t *rowptr,
+               const int32_t *colidx, const double *val, SplitCsr &out);
+
+// ---------------------------------------------------------------------------
+// Krylov state that lives in device memory (one per context)
+// ---------------------------------------------------------------------------
+struct KrylovState {
+    int32_t its, reason, done, loc_done;
+    int32_t max_it, restart, hapend, pad0;
+    double rnorm, rnorm0, ttol, abstol, dtol, bnorm;
+    double inv_tt;  // 1/||w|| of the last orthogonalised vector (or 1/||r||)
+    double tt;
+};
+
+// kernel launch wrappers (spk_kernels.hip)
+namespace k {
+constexpr int kMaxNv = 64;       // max vectors in one mdot/maxpy launch (restart <= 63)
+constexpr int kPartialLd = 64;   // leading dimension of block partials
+constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
+
+void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row);
+
+// y = A x  (+ Bt-rows * lam when bt != nullptr); CSR stream kernel
+void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+          const int32_t *done, hipStream_t s);
+// y[rows[i]] += Ao_row_i . xg   (compressed off-rank block)
+void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
+                  const int32_t *done, hipStream_t s);
+// partial[w*m + r] = sum over window w of B_r . x ; then reduce_partials
+void wide_dot(const WideDev &B, const double *x, double *partials, const int32_t *done, hipStream_t s);
+// same with x replaced by x .* dinv (the B D x0 step of the Schur PC, no stored D x0)
+void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, double *partials,
+                     const int32_t *done, hipStream_t s);
+// dense[col] = val*dinv[col] over entries [k0,k1) of B (dinv == nullptr: dense[col] = 0)
+void scatter_row(const int32_t *colidx, const double *val, int k0, int k1, const double *dinv,
+                 double *dense, hipStream_t s);
+// out[i] = sum_r slots[r*ld + i] in rank order (local-group all-reduce)
+void sum_slots(const double *slots, int nslots, int ld, int count, double *out, hipStream_t s);
+// out[i] = sum_b partials[b*ld + i], fixed order
+void reduce_partials(const double *partials, int nb, int ld, int k, double *out,
+                     const int32_t *done, hipStream_t s);
+// h partials for i < nv:  V_i . w ; plus w.w at slot nv
+void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
+          double *partials, int *nblocks, const int32_t *done, hipStream_t s);
+// w += sum_i coef_sign * a[i] * V_i ; partials of ||w_new||^2 (first n_dot entries)
+void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
+           double coef_sign, double *w, int64_t n, int64_t n_dot, double *partials, int *nblocks,
+           const int32_t *done, hipStream_t s);
+// x *= *alpha_dev
+void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s);
+// y = a*x + b*y with host scalars (b = 0: y = a*x without reading y)
+void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s);
+// partials of x.x over the first n_dot entries
+void sqnorm(const double *x, int64_t n_dot, double *partials, int *nblocks, const int32_t *done,
+            hipStream_t s);
+// gather x[idx[i]] -> out[i]
+void gather(const double *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s);
+// Jacobi / Schur pieces
+void jacobi(const double *dinv, const double *x, double *y, int64_t n, const int32_t *done, hipStream_t s);
+void extract_diag_inv(const CsrDev &A, double *dinv, hipStream_t s);
+// y0 = dinv .* (x0 - Bt y1)            (mode 0, UPPER)
+// y0 = dinv .* x0 - dinv .* (Bt y1)    (mode 1, FULL third step, recomputing D x0)
+void bt_update(int mode, const CsrDev &Bt, const double *dinv, const double *x0, const double *y1,
+               double *y0, const int32_t *done, hipStream_t s);
+// small scalar kernels
+void schur_y1(int fact, int m, const double *x1, const double *t, const double *shat, double *y1,
+              const int32_t *done, hipStream_t s);
+void copy_small(const double *src, double *dst, int n, const int32_t *done, hipStream_t s);
+
+// Krylov scalar kernels (single wave)
+struct KrylovArrays {
+    KrylovState *st;
+    double *H, *cc, *ss, *rs, *nrs, *hcol, *hist;
+    int32_t hist_cap, ldh;
+};
+void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s);
+void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
+}  // namespace k
+
+}  // namespace spk
+
+// ---------------------------------------------------------------------------
+// the context
+// ---------------------------------------------------------------------------
+struct spk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    std::unique_ptr<spk::Comm> comm;
+
+    // sizes
+    int64_t n_global = 0, row_begin = 0;
+    int32_t n_local = 0, m = 0, n_ghost = 0;
+    int64_t ld = 0;  // padded vector length (n_local + m rounded up)
+
+    // (0,0) block: diagonal part, compressed off-rank part
+    spk::CsrDev Ad, Ao;
+    spk::DevBuf<int32_t> ao_rows;  // local row of each compressed Ao row
+    bool have_A = false, have_B = false;
+
+    // constraint block: B (m x n_local) in column windows, B^T (n_local x m) by rows
+    spk::WideDev B;
+    spk::CsrDev Bt;
+
+    // halo plan
+    std::vector<int> peers;
+    std::vector<int64_t> send_off, recv_off;  // per peer offsets (+ total at end)
+    spk::DevBuf<int32_t> send_idx;
+    spk::DevBuf<double> send_buf, xghost;
+
+    // preconditioner
+    int pc_type = SPK_PC_NONE, schur_fact = SPK_SCHUR_FULL;
+    bool pc_ready = false;
+    spk::DevBuf<double> dinv, shat, gram;  // n_local, m, m*m
+
+    // scratch
+    spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd
+    spk::DevBuf<double> small;     // reduced scalars (256 doubles)
+    spk::DevBuf<double> y1tmp, ttmp;
+
+    // Krylov workspace (sized by restart)
+    int ws_restart = -1;
+    spk::DevBuf<double> V, Z, xsol, rhs, tmp;
+    spk::DevBuf<double> kry_d;  // H, cc, ss, rs, nrs, hcol, hist
+    spk::DevBuf<spk::KrylovState> kst;
+    spk::k::KrylovArrays ka{};
+
+    // staging for host-pointer entry points
+    spk::DevBuf<double> stage_x, stage_y;
+
+    void ensure_scratch();
+    void ensure_vectors();
+};
+
+namespace spk {
+// solver pieces used by the API layer (spk_solver.cpp)
+void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done);
+void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done);
+void pc_setup(spk_ctx *c, int pc_type, int schur_fact);
+void fgmres(spk_ctx *c, const double *b_dev, double *x_dev, const spk_opts &o, spk_result *res,
+            double *history, int32_t history_cap);
+void set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
+               const int32_t *rowptr, const int32_t *colidx, const double *val);
+}  // namespace spk

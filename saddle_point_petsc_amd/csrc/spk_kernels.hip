@@ -1,0 +1,795 @@
+// spk_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the
+// KSPSolve hot path.  Every kernel here is HBM-bandwidth bound (FP64 streams,
+// ~0.17 flop/B): no MFMA, the levers are 16-byte coalesced loads, LDS-staged
+// partial sums, wave-64 shuffle reductions, XCD-contiguous tile placement and
+// fixed-order (deterministic) cross-workgroup reductions.
+//
+// What each kernel replaces inside PETSc (reached from
+// /root/reference/src/SaddlePointProblem.c:70):
+//   spmv_stream_kernel   MatMult_SeqAIJ on the A block (+ MatMultTransposeAdd of B)
+//   spmv_offdiag_kernel  the off-process part of MatMult_MPIAIJ
+//   wide_dot_kernel      MatMult_SeqAIJ on the 4 long rows of B
+//   mdot_kernel          VecMDot (+ the squared norm of w in the same pass)
+//   maxpy_kernel         VecMAXPY (+ VecNorm of the result in the same pass)
+//   scale/axpby/jacobi   VecScale, VecAXPY/WAXPY, PCApply_Jacobi
+//   bt_update/schur_y1   the block steps of PCApply_FieldSplit_Schur
+//   krylov_*             KSPFGMRESCycle's scalar work: Hessenberg column,
+//                        Givens rotations, convergence test, back substitution
+#include "spk_internal.hpp"
+
+#include <cmath>
+
+namespace spk {
+namespace k {
+
+constexpr int kThreads = 256;
+constexpr int kWave = 64;
+constexpr int kTileNnz = 4096;   // products staged in LDS per workgroup: 32 KiB
+constexpr int kTileRows = 256;   // rows per tile <= threads
+constexpr int kVecUnroll = 4;    // double2 per thread per vector tile
+constexpr int kVecTile2 = kThreads * kVecUnroll;  // double2 per tile (2048 doubles)
+
+// ---------------------------------------------------------------------------
+// reductions inside a workgroup
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// CSR stream SpMV (A block).  One workgroup = one row tile whose non-zeros
+// (<= 4096) are streamed with 16-byte loads, multiplied by gathered x and
+// staged in LDS; then one thread per row adds its products in CSR order --
+// the same order and roundings as a sequential CSR loop.
+// Arrays are padded by >= 8 entries so whole quads can be loaded unguarded.
+// ---------------------------------------------------------------------------
+void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row)
+{
+    tile_row.clear();
+    tile_row.push_back(0);
+    int32_t r = 0;
+    while (r < nrows) {
+        const int32_t r0 = r;
+        const int64_t a0 = (int64_t)rowptr[r0] & ~(int64_t)3;
+        while (r < nrows && (r - r0) < kTileRows && ((int64_t)rowptr[r + 1] - a0) <= kTileNnz) ++r;
+        if (r == r0) ++r;  // one row longer than a tile: long-row path
+        tile_row.push_back(r);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+    const double *__restrict__ val, const int32_t *__restrict__ tile_row, int ntiles,
+    int tiles_per_xcd, const double *__restrict__ x, double *__restrict__ y,
+    const int32_t *__restrict__ bt_rowptr, const int32_t *__restrict__ bt_colidx,
+    const double *__restrict__ bt_val, const double *__restrict__ lam,
+    const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    // workgroups b, b+8, ... share an XCD (round-robin dispatch): give each XCD
+    // a contiguous run of row tiles so the x window stays in ITS L2.
+    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || t >= ntiles) return;
+
+    __shared__ double prod[kTileNnz + 8];
+    const int r0 = tile_row[t], r1 = tile_row[t + 1];
+    const int nz0 = rowptr[r0], nz1 = rowptr[r1];
+    const int a0 = nz0 & ~3;
+    const int cnt = nz1 - a0;
+
+    if (cnt > kTileNnz) {
+        // a single row longer than a tile: strided partial sums + block reduce
+        double acc[1] = {0.0};
+        for (int k = nz0 + threadIdx.x; k < nz1; k += kThreads) acc[0] += val[k] * x[colidx[k]];
+        double out1;
+        __shared__ double red[4];
+        const double s = wave_sum(acc[0]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            out1 = ((red[0] + red[1]) + red[2]) + red[3];
+            if (bt_rowptr)
+                for (int k = bt_rowptr[r0]; k < bt_rowptr[r0 + 1]; ++k) out1 += bt_val[k] * lam[bt_colidx[k]];
+            y[r0] = out1;
+        }
+        return;
+    }
+
+    // phase 1: issue every load of the tile first, then gather x, then stage.
+    constexpr int kSteps = kTileNnz / (kThreads * 4);  // 4
+    int4 c[kSteps];
+    double2 v0[kSteps], v1[kSteps];
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int q = (i * kThreads + threadIdx.x) * 4;
+        if (q < cnt) {
+            c[i] = *reinterpret_cast<const int4 *>(colidx + a0 + q);
+            v0[i] = *reinterpret_cast<const double2 *>(val + a0 + q);
+            v1[i] = *reinterpret_cast<const double2 *>(val + a0 + q + 2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int q = (i * kThreads + threadIdx.x) * 4;
+        if (q < cnt) {
+            double2 p0, p1;
+            p0.x = v0[i].x * x[c[i].x];
+            p0.y = v0[i].y * x[c[i].y];
+            p1.x = v1[i].x * x[c[i].z];
+            p1.y = v1[i].y * x[c[i].w];
+            *reinterpret_cast<double2 *>(prod + q) = p0;
+            *reinterpret_cast<double2 *>(prod + q + 2) = p1;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: one thread per row, CSR order
+    const int r = r0 + threadIdx.x;
+    if (r < r1) {
+        const int k0 = rowptr[r] - a0, k1 = rowptr[r + 1] - a0;
+        double s = 0.0;
+        for (int k = k0; k < k1; ++k) s += prod[k];
+        if (bt_rowptr)
+            for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
+        y[r] = s;
+    }
+}
+
+void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+          const int32_t *done, hipStream_t s)
+{
+    if (A.nrows == 0) return;
+    const int tpx = (A.ntiles + 7) / 8;
+    hipLaunchKernelGGL(spmv_stream_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p,
+                       A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y,
+                       bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr,
+                       bt ? bt->val.p : nullptr, lam, done);
+}
+
+// compressed off-rank block: few short rows, one thread per row
+__global__ __launch_bounds__(kThreads) void spmv_offdiag_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+    const double *__restrict__ val, const int32_t *__restrict__ rows, int nrows,
+    const double *__restrict__ xg, double *__restrict__ y, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= nrows) return;
+    double s = 0.0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * xg[colidx[k]];
+    y[rows[i]] += s;
+}
+
+void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
+                  const int32_t *done, hipStream_t s)
+{
+    if (Ao.nrows == 0) return;
+    hipLaunchKernelGGL(spmv_offdiag_kernel, dim3((Ao.nrows + kThreads - 1) / kThreads), dim3(kThreads),
+                       0, s, Ao.rowptr.p, Ao.colidx.p, Ao.val.p, rows, Ao.nrows, xg, y, done);
+}
+
+// ---------------------------------------------------------------------------
+// B x for the short-and-wide constraint block: one workgroup per column window,
+// all m rows, so x (optionally x .* scale) is streamed once.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void wide_dot_kernel(
+    const int32_t *__restrict__ colidx, const double *__restrict__ val,
+    const int32_t *__restrict__ winptr, int m, const double *__restrict__ x,
+    const double *__restrict__ scale, double *__restrict__ partials, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double red[4];
+    const int w = blockIdx.x;
+    for (int r = 0; r < m; ++r) {
+        const int k0 = winptr[w * m + r], k1 = winptr[(w + 1) * m + r];
+        double acc = 0.0;
+        if (scale) {
+            for (int k = k0 + threadIdx.x; k < k1; k += kThreads) {
+                const int c = colidx[k];
+                acc += val[k] * (x[c] * scale[c]);
+            }
+        } else {
+            for (int k = k0 + threadIdx.x; k < k1; k += kThreads) acc += val[k] * x[colidx[k]];
+        }
+        const double s = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[(size_t)w * kPartialLd + r] = ((red[0] + red[1]) + red[2]) + red[3];
+        __syncthreads();
+    }
+}
+
+static void wide_dot_scaled(const WideDev &B, const double *x, const double *scale, double *partials,
+                            const int32_t *done, hipStream_t s)
+{
+    if (B.nwin == 0) return;
+    hipLaunchKernelGGL(wide_dot_kernel, dim3(B.nwin), dim3(kThreads), 0, s, B.colidx.p, B.val.p,
+                       B.winptr.p, B.m, x, scale, partials, done);
+}
+void wide_dot(const WideDev &B, const double *x, double *partials, const int32_t *done, hipStream_t s)
+{
+    wide_dot_scaled(B, x, nullptr, partials, done, s);
+}
+void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, double *partials,
+                     const int32_t *done, hipStream_t s)
+{
+    wide_dot_scaled(B, x, dinv, partials, done, s);
+}
+
+// out[i] = sum_b partials[b*ld + i], i < k <= 64: 16 strided slices, then a
+// fixed-order finish -> bitwise reproducible.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__restrict__ partials,
+                                                               int nb, int ld, int k,
+                                                               double *__restrict__ out,
+                                                               const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double sl[16][64];
+    const int i = threadIdx.x & 63, sidx = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (i < k)
+        for (int b = sidx; b < nb; b += 16) acc += partials[(size_t)b * ld + i];
+    sl[sidx][i] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < k) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += sl[j][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+void reduce_partials(const double *partials, int nb, int ld, int k, double *out, const int32_t *done,
+                     hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partials, nb, ld, k, out, done);
+}
+
+// ---------------------------------------------------------------------------
+// VecMDot: all nv dot products V_i . w in ONE pass over w (kept in registers),
+// plus w.w in slot nv.  Template NG = groups of 8 vectors (static accumulators).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 ld2(const double *p, int64_t i2)
+{
+    return reinterpret_cast<const double2 *>(p)[i2];
+}
+
+template <int NG>
+__global__ __launch_bounds__(kThreads) void mdot_kernel(const double *__restrict__ V, int64_t ldv,
+                                                        int nv, const double *__restrict__ w,
+                                                        int64_t n2, int64_t n_dot,
+                                                        double *__restrict__ partials, int with_ww,
+                                                        const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double lds[4 * (NG * 8 + 1)];
+    double acc[NG * 8 + 1];
+#pragma unroll
+    for (int i = 0; i < NG * 8 + 1; ++i) acc[i] = 0.0;
+
+    for (int64_t tile = blockIdx.x; tile * kVecTile2 < n2; tile += gridDim.x) {
+        double2 wv[kVecUnroll];
+        int64_t idx[kVecUnroll];
+#pragma unroll
+        for (int u = 0; u < kVecUnroll; ++u) {
+            idx[u] = tile * kVecTile2 + u * kThreads + threadIdx.x;
+            if (idx[u] < n2) {
+                wv[u] = ld2(w, idx[u]);
+                if (2 * idx[u] >= n_dot) wv[u].x = 0.0;
+                if (2 * idx[u] + 1 >= n_dot) wv[u].y = 0.0;
+            } else {
+                wv[u].x = wv[u].y = 0.0;
+                idx[u] = 0;  // safe address, zero weight
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kVecUnroll; ++u) acc[NG * 8] += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g * 8 < nv) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int i = g * 8 + v;
+                    if (i < nv) {
+                        const double *Vi = V + (size_t)i * ldv;
+                        double2 a[kVecUnroll];
+#pragma unroll
+                        for (int u = 0; u < kVecUnroll; ++u) a[u] = ld2(Vi, idx[u]);
+#pragma unroll
+                        for (int u = 0; u < kVecUnroll; ++u) acc[i] += a[u].x * wv[u].x + a[u].y * wv[u].y;
+                    }
+                }
+            }
+        }
+    }
+    // workgroup sums -> partials[block][i]; w.w goes to slot nv
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NG * 8 + 1; ++i) {
+        const double s = wave_sum(acc[i]);
+        if (lane == 0) lds[wave * (NG * 8 + 1) + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NG * 8 + 1) {
+        const int i = threadIdx.x;
+        const double s = ((lds[i] + lds[(NG * 8 + 1) + i]) + lds[2 * (NG * 8 + 1) + i]) + lds[3 * (NG * 8 + 1) + i];
+        double *row = partials + (size_t)blockIdx.x * kPartialLd;
+        if (i < nv) row[i] = s;
+        else if (i == NG * 8 && with_ww) row[nv] = s;
+    }
+}
+
+static int vec_grid(int64_t n2)
+{
+    int64_t tiles = (n2 + kVecTile2 - 1) / kVecTile2;
+    if (tiles < 1) tiles = 1;
+    return (int)(tiles < kMaxBlocks ? tiles : kMaxBlocks);
+}
+
+void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
+          double *partials, int *nblocks, const int32_t *done, hipStream_t s)
+{
+    if (nv > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: nv=%d exceeds %d", nv, kMaxNv - 1);
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = vec_grid(n2);
+    *nblocks = grid;
+    // up to 32 vectors per launch; w.w is produced by the last launch
+    int v0 = 0;
+    do {
+        const int cnt = (nv - v0) < 32 ? (nv - v0) : 32;
+        const int last = (v0 + 32 >= nv);
+        const double *Vp = V + (size_t)v0 * ldv;
+        double *pp = partials + v0;
+        const int ng = cnt <= 8 ? 1 : cnt <= 16 ? 2 : cnt <= 24 ? 3 : 4;
+        switch (ng) {
+        case 1: hipLaunchKernelGGL(mdot_kernel<1>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
+        case 2: hipLaunchKernelGGL(mdot_kernel<2>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
+        case 3: hipLaunchKernelGGL(mdot_kernel<3>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
+        default: hipLaunchKernelGGL(mdot_kernel<4>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
+        }
+        v0 += 32;
+    } while (v0 < nv);
+}
+
+// ---------------------------------------------------------------------------
+// VecMAXPY:  w += sign * sum_i a[i] V_i, coefficients read from device memory;
+// the squared norm of the updated w (first n_dot entries) is produced in the
+// same pass -> VecNorm costs no extra sweep.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void maxpy_kernel(const double *__restrict__ V, int64_t ldv,
+                                                         int nv, const int32_t *__restrict__ nv_dev,
+                                                         const double *__restrict__ a, double sign,
+                                                         double *__restrict__ w, int64_t n2,
+                                                         int64_t n_dot, double *__restrict__ partials,
+                                                         const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    if (nv_dev) nv = *nv_dev;
+    __shared__ double red[4];
+    double nrm = 0.0;
+    for (int64_t tile = blockIdx.x; tile * kVecTile2 < n2; tile += gridDim.x) {
+        double2 wv[kVecUnroll];
+        int64_t idx[kVecUnroll];
+        bool ok[kVecUnroll];
+#pragma unroll
+        for (int u = 0; u < kVecUnroll; ++u) {
+            idx[u] = tile * kVecTile2 + u * kThreads + threadIdx.x;
+            ok[u] = idx[u] < n2;
+            if (!ok[u]) idx[u] = 0;
+            wv[u] = ld2(w, idx[u]);
+        }
+#pragma unroll 4
+        for (int i = 0; i < nv; ++i) {
+            const double ai = sign * a[i];
+            const double *Vi = V + (size_t)i * ldv;
+            double2 t[kVecUnroll];
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) t[u] = ld2(Vi, idx[u]);
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) {
+                wv[u].x += ai * t[u].x;
+                wv[u].y += ai * t[u].y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kVecUnroll; ++u) {
+            if (ok[u]) {
+                reinterpret_cast<double2 *>(w)[idx[u]] = wv[u];
+                if (2 * idx[u] < n_dot) nrm += wv[u].x * wv[u].x;
+                if (2 * idx[u] + 1 < n_dot) nrm += wv[u].y * wv[u].y;
+            }
+        }
+    }
+    const double s = wave_sum(nrm);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialLd] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
+           double coef_sign, double *w, int64_t n, int64_t n_dot, double *partials, int *nblocks,
+           const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = vec_grid(n2);
+    *nblocks = grid;
+    hipLaunchKernelGGL(maxpy_kernel, dim3(grid), dim3(kThreads), 0, s, V, ldv, nv, nv_dev, a, coef_sign,
+                       w, n2, n_dot, partials, done);
+}
+
+// ---------------------------------------------------------------------------
+// level-1 streams
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void scale_dev_kernel(double *__restrict__ x, int64_t n2,
+                                                             const double *__restrict__ alpha,
+                                                             const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const double a = *alpha;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+        double2 v = reinterpret_cast<double2 *>(x)[i];
+        v.x *= a;
+        v.y *= a;
+        reinterpret_cast<double2 *>(x)[i] = v;
+    }
+}
+void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, x, n2, alpha_dev, done);
+}
+
+__global__ __launch_bounds__(kThreads) void axpby_kernel(double a, const double *__restrict__ x,
+                                                         double b, double *__restrict__ y, int64_t n2,
+                                                         const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+        const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+        double2 yv;
+        if (b == 0.0) {
+            yv.x = a * xv.x;
+            yv.y = a * xv.y;
+        } else {
+            yv = reinterpret_cast<double2 *>(y)[i];
+            yv.x = a * xv.x + b * yv.x;
+            yv.y = a * xv.y + b * yv.y;
+        }
+        reinterpret_cast<double2 *>(y)[i] = yv;
+    }
+}
+void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, a, x, b, y, n2, done);
+}
+
+__global__ __launch_bounds__(kThreads) void sqnorm_kernel(const double *__restrict__ x, int64_t n2,
+                                                          int64_t n_dot, double *__restrict__ partials,
+                                                          const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+        const double2 v = reinterpret_cast<const double2 *>(x)[i];
+        if (2 * i < n_dot) acc += v.x * v.x;
+        if (2 * i + 1 < n_dot) acc += v.y * v.y;
+    }
+    const double s = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialLd] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+void sqnorm(const double *x, int64_t n_dot, double *partials, int *nblocks, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = (n_dot + 1) / 2;
+    const int grid = vec_grid(n2);
+    *nblocks = grid;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kThreads), 0, s, x, n2, n_dot, partials, done);
+}
+
+__global__ __launch_bounds__(kThreads) void gather_kernel(const double *__restrict__ x,
+                                                          const int32_t *__restrict__ idx, int64_t n,
+                                                          double *__restrict__ out,
+                                                          const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) out[i] = x[idx[i]];
+}
+void gather(const double *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, x, idx, n, out, done);
+}
+
+// ---------------------------------------------------------------------------
+// preconditioner pieces
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void jacobi_kernel(const double *__restrict__ dinv,
+                                                          const double *__restrict__ x,
+                                                          double *__restrict__ y, int64_t n,
+                                                          const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+        y[i] = x[i] * dinv[i];
+}
+void jacobi(const double *dinv, const double *x, double *y, int64_t n, const int32_t *done, hipStream_t s)
+{
+    if (n == 0) return;
+    const int grid = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(jacobi_kernel, dim3(grid), dim3(kThreads), 0, s, dinv, x, y, n, done);
+}
+
+// PCJACOBI set-up: inverse diagonal, zero -> 1
+__global__ __launch_bounds__(kThreads) void extract_diag_inv_kernel(const int32_t *__restrict__ rowptr,
+                                                                    const int32_t *__restrict__ colidx,
+                                                                    const double *__restrict__ val,
+                                                                    int nrows, double *__restrict__ dinv)
+{
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= nrows) return;
+    double d = 0.0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (colidx[k] == r) d = val[k];
+    dinv[r] = (d == 0.0) ? 1.0 : 1.0 / d;
+}
+void extract_diag_inv(const CsrDev &A, double *dinv, hipStream_t s)
+{
+    if (A.nrows == 0) return;
+    hipLaunchKernelGGL(extract_diag_inv_kernel, dim3((A.nrows + kThreads - 1) / kThreads), dim3(kThreads),
+                       0, s, A.rowptr.p, A.colidx.p, A.val.p, A.nrows, dinv);
+}
+
+// mode 0:  y0 = dinv .* (x0 - Bt y1)          (UPPER)
+// mode 1:  y0 = dinv .* x0 - dinv .* (Bt y1)  (FULL, third step)
+__global__ __launch_bounds__(kThreads) void bt_update_kernel(int mode,
+                                                             const int32_t *__restrict__ rowptr,
+                                                             const int32_t *__restrict__ colidx,
+                                                             const double *__restrict__ val, int nrows,
+                                                             const double *__restrict__ dinv,
+                                                             const double *__restrict__ x0,
+                                                             const double *__restrict__ y1,
+                                                             double *__restrict__ y0,
+                                                             const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int r = blockIdx.x * kThreads + threadIdx.x; r < nrows; r += gridDim.x * kThreads) {
+        double c = 0.0;
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += val[k] * y1[colidx[k]];
+        const double d = dinv[r], xv = x0[r];
+        y0[r] = (mode == 0) ? (xv - c) * d : xv * d - c * d;
+    }
+}
+void bt_update(int mode, const CsrDev &Bt, const double *dinv, const double *x0, const double *y1,
+               double *y0, const int32_t *done, hipStream_t s)
+{
+    if (Bt.nrows == 0) return;
+    const int grid = std::min((Bt.nrows + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(bt_update_kernel, dim3(grid), dim3(kThreads), 0, s, mode, Bt.rowptr.p, Bt.colidx.p,
+                       Bt.val.p, Bt.nrows, dinv, x0, y1, y0, done);
+}
+
+// the m-vector step of PCApply_FieldSplit_Schur with S~ = -S^:
+//   DIAG : y1 =  x1 / S^        LOWER/FULL: y1 = -(x1 - t) / S^     UPPER: y1 = -x1 / S^
+__global__ void schur_y1_kernel(int fact, int m, const double *__restrict__ x1,
+                                const double *__restrict__ t, const double *__restrict__ shat,
+                                double *__restrict__ y1, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const int r = threadIdx.x;
+    if (r >= m) return;
+    double v;
+    if (fact == SPK_SCHUR_DIAG) v = x1[r] / shat[r];
+    else if (fact == SPK_SCHUR_UPPER) v = -x1[r] / shat[r];
+    else v = -(x1[r] - t[r]) / shat[r];
+    y1[r] = v;
+}
+void schur_y1(int fact, int m, const double *x1, const double *t, const double *shat, double *y1,
+              const int32_t *done, hipStream_t s)
+{
+    if (m == 0) return;
+    hipLaunchKernelGGL(schur_y1_kernel, dim3(1), dim3(64), 0, s, fact, m, x1, t, shat, y1, done);
+}
+
+__global__ void copy_small_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
+                                  const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+void copy_small(const double *src, double *dst, int n, const int32_t *done, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(copy_small_kernel, dim3(1), dim3(64), 0, s, src, dst, n, done);
+}
+
+// dense scatter of one B row scaled by dinv (set-up of S^ and G only)
+__global__ __launch_bounds__(kThreads) void scatter_row_kernel(const int32_t *__restrict__ colidx,
+                                                               const double *__restrict__ val, int k0,
+                                                               int k1, const double *__restrict__ dinv,
+                                                               double *__restrict__ dense)
+{
+    const int k = k0 + blockIdx.x * kThreads + threadIdx.x;
+    if (k < k1) dense[colidx[k]] = dinv ? val[k] * dinv[colidx[k]] : 0.0;
+}
+void scatter_row(const int32_t *colidx, const double *val, int k0, int k1, const double *dinv,
+                 double *dense, hipStream_t s)
+{
+    if (k1 <= k0) return;
+    hipLaunchKernelGGL(scatter_row_kernel, dim3((k1 - k0 + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       colidx, val, k0, k1, dinv, dense);
+}
+
+__global__ void sum_slots_kernel(const double *__restrict__ slots, int nslots, int ld, int count,
+                                 double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int r = 0; r < nslots; ++r) s += slots[(size_t)r * ld + i];
+    out[i] = s;
+}
+void sum_slots(const double *slots, int nslots, int ld, int count, double *out, hipStream_t s)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(sum_slots_kernel, dim3((count + 63) / 64), dim3(64), 0, s, slots, nslots, ld, count, out);
+}
+
+// ---------------------------------------------------------------------------
+// Krylov scalar work on the device (one thread): the host never waits for a
+// Hessenberg entry, it only enqueues.  Semantics: PETSc KSPFGMRESCycle /
+// KSPFGMRESUpdateHessenberg / KSPFGMRESBuildSoln / KSPConvergedDefault.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int converged_default(double rnorm, const KrylovState *st)
+{
+    if (isnan(rnorm) || isinf(rnorm)) return SPK_DIVERGED_NANORINF;
+    if (rnorm <= st->ttol) return (rnorm < st->abstol) ? SPK_CONVERGED_ATOL : SPK_CONVERGED_RTOL;
+    if (rnorm >= st->dtol * st->rnorm0) return SPK_DIVERGED_DTOL;
+    return 0;
+}
+
+__global__ void krylov_init_kernel(KrylovArrays ka, spk_opts o, const double *bnorm2)
+{
+    if (threadIdx.x != 0) return;
+    KrylovState *st = ka.st;
+    st->its = 0;
+    st->reason = 0;
+    st->done = 0;
+    st->loc_done = 0;
+    st->max_it = o.max_it;
+    st->restart = o.restart;
+    st->hapend = 0;
+    st->bnorm = sqrt(*bnorm2);
+    st->abstol = o.abstol;
+    st->dtol = o.dtol;
+    st->ttol = fmax(o.rtol * st->bnorm, o.abstol);
+    st->rnorm = 0.0;
+    st->rnorm0 = 0.0;
+    st->inv_tt = 1.0;
+    st->tt = 0.0;
+}
+void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_init_kernel, dim3(1), dim3(64), 0, s, ka, o, bnorm2);
+}
+
+__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2)
+{
+    if (threadIdx.x != 0) return;
+    KrylovState *st = ka.st;
+    st->loc_done = 0;
+    if (st->done) return;
+    const double rnorm = sqrt(*nrm2);
+    st->rnorm = rnorm;
+    if (st->its == 0) {
+        st->rnorm0 = rnorm;
+        if (ka.hist_cap > 0) ka.hist[0] = rnorm;
+    }
+    int reason = converged_default(rnorm, st);
+    if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
+    st->reason = reason;
+    st->hapend = 0;
+    if (reason) {
+        st->done = 1;
+        return;
+    }
+    ka.rs[0] = rnorm;
+    st->inv_tt = 1.0 / rnorm;
+}
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2);
+}
+
+__global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
+{
+    if (threadIdx.x != 0) return;
+    KrylovState *st = ka.st;
+    if (st->done) return;
+    const int ldh = ka.ldh;
+    double *Hc = ka.H + (size_t)ldh * loc;  // column loc
+    const double tt = sqrt(*nrm2);
+    for (int j = 0; j <= loc; ++j) Hc[j] = dots[j];
+    // happy breakdown test
+    double hapbnd = fabs(tt / ka.rs[loc]);
+    if (hapbnd > 1e-30) hapbnd = 1e-30;
+    const int hapend = !(tt > hapbnd);
+    Hc[loc + 1] = tt;
+    st->tt = tt;
+    st->inv_tt = hapend ? 1.0 : 1.0 / tt;
+    // previous rotations on the new column
+    for (int j = 1; j <= loc; ++j) {
+        const double h0 = Hc[j - 1], h1 = Hc[j];
+        Hc[j - 1] = ka.cc[j - 1] * h0 + ka.ss[j - 1] * h1;
+        Hc[j] = ka.cc[j - 1] * h1 - ka.ss[j - 1] * h0;
+    }
+    double rnorm;
+    int reason = 0;
+    if (!hapend) {
+        const double h0 = Hc[loc], h1 = Hc[loc + 1];
+        const double d = sqrt(h0 * h0 + h1 * h1);
+        if (d == 0.0) {
+            st->reason = SPK_DIVERGED_NULL;
+            st->done = 1;
+            return;
+        }
+        const double c = h0 / d, sn = h1 / d;
+        ka.cc[loc] = c;
+        ka.ss[loc] = sn;
+        ka.rs[loc + 1] = -sn * ka.rs[loc];
+        ka.rs[loc] = c * ka.rs[loc];
+        Hc[loc] = c * h0 + sn * h1;
+        rnorm = fabs(ka.rs[loc + 1]);
+    } else {
+        rnorm = 0.0;
+    }
+    st->its += 1;
+    st->loc_done = loc + 1;
+    st->rnorm = rnorm;
+    st->hapend = hapend;
+    if (st->its < ka.hist_cap) ka.hist[st->its] = rnorm;
+    reason = converged_default(rnorm, st);
+    if (hapend && !reason) reason = SPK_DIVERGED_BREAKDOWN;
+    if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
+    st->reason = reason;
+    if (reason) st->done = 1;
+}
+void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2);
+}
+
+// back substitution for the loc_done columns built in this cycle
+__global__ void krylov_cycle_end_kernel(KrylovArrays ka)
+{
+    if (threadIdx.x != 0) return;
+    KrylovState *st = ka.st;
+    const int n = st->loc_done, ldh = ka.ldh;
+    for (int k = n - 1; k >= 0; --k) {
+        double t = ka.rs[k];
+        for (int j = k + 1; j < n; ++j) t -= ka.H[(size_t)ldh * j + k] * ka.nrs[j];
+        const double piv = ka.H[(size_t)ldh * k + k];
+        if (piv == 0.0) {
+            if (st->reason >= 0) st->reason = SPK_DIVERGED_BREAKDOWN;
+            st->done = 1;
+            st->loc_done = 0;
+            return;
+        }
+        ka.nrs[k] = t / piv;
+    }
+}
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(64), 0, s, ka);
+}
+
+}  // namespace k
+}  // namespace spk

@@ -1,0 +1,455 @@
+// spk_solver.cpp -- operator, preconditioner and the device-resident FGMRES.
+//
+// Replaces what executes below KSPSolve(ksp, f, *u) at
+// /root/reference/src/SaddlePointProblem.c:70 when the reference is run with
+// -ksp_type fgmres -pc_type fieldsplit -pc_fieldsplit_type schur ... (options
+// read at :67): PETSc's KSPSolve_FGMRES drives the loop from the host and waits
+// on every dot product; here the host only ENQUEUES a whole restart cycle on
+// one HIP stream.  The Hessenberg column, the Givens rotations, the convergence
+// test and the back substitution run in single-wave kernels on the device, and
+// every kernel of an iteration starts with "if (*done) return", so the iterate
+// is exactly the one a stop-at-convergence loop would produce while the host
+// looks at the state only once per cycle (or every opts.check_every
+// iterations).  Inner products across ranks go through Comm::allreduce_sum on
+// the same stream (RCCL), never through the host.
+#include <algorithm>
+#include <chrono>
+#include <cstddef>
+#include <cstring>
+#include <numeric>
+
+#include "spk_internal.hpp"
+
+using namespace spk;
+
+void spk_ctx::ensure_scratch()
+{
+    if (!partials.p) partials.alloc((size_t)k::kMaxBlocks * k::kPartialLd);
+    if (!small.p) small.alloc(512);
+    if (!y1tmp.p) y1tmp.alloc(64);
+    if (!ttmp.p) ttmp.alloc(64);
+}
+
+void spk_ctx::ensure_vectors()
+{
+    const int64_t want = ((int64_t)n_local + m + 255) / 256 * 256;
+    if (want != ld) {
+        ld = want;
+        ws_restart = -1;
+        tmp.release();
+        stage_x.release();
+        stage_y.release();
+        xsol.release();
+        rhs.release();
+    }
+    if (!tmp.p) tmp.alloc((size_t)ld);
+    if (!xsol.p) xsol.alloc((size_t)ld);
+    if (!rhs.p) rhs.alloc((size_t)ld);
+    if (!stage_x.p) stage_x.alloc((size_t)ld);
+    if (!stage_y.p) stage_y.alloc((size_t)ld);
+}
+
+namespace spk {
+
+// ---------------------------------------------------------------------------
+// KSPSetOperators: upload one block (SaddlePointProblem.c:66; the nest at :45-60)
+// ---------------------------------------------------------------------------
+static void upload_csr(CsrDev &D, int32_t nrows, int32_t ncols, const std::vector<int32_t> &rowptr,
+                       const std::vector<int32_t> &colidx, const std::vector<double> &val, bool tiles)
+{
+    D.nrows = nrows;
+    D.ncols = ncols;
+    D.nnz = (int64_t)colidx.size();
+    D.rowptr.upload(rowptr.data(), rowptr.size(), 8);
+    D.colidx.upload(colidx.data(), colidx.size(), 16);
+    D.val.upload(val.data(), val.size(), 16);
+    if (tiles) {
+        std::vector<int32_t> tr;
+        k::build_tiles(rowptr.data(), nrows, tr);
+        D.ntiles = (int32_t)tr.size() - 1;
+        D.tile_row.upload(tr.data(), tr.size(), 8);
+    }
+}
+
+static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
+                        const int32_t *rowptr, const int32_t *colidx, const double *val)
+{
+    if (rowptr[0] != 0) fail(SPK_ERR_ARG, "A00: rowptr[0] must be 0");
+    const int64_t nnz = rowptr[nrows_local];
+    for (int64_t k = 0; k < nnz; ++k)
+        if (colidx[k] < 0 || colidx[k] >= ncols_global)
+            fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", colidx[k], (long long)ncols_global);
+    if (row_begin < 0 || row_begin + nrows_local > ncols_global)
+        fail(SPK_ERR_ARG, "A00: rows [%lld,%lld) outside the %lld x %lld block", (long long)row_begin,
+             (long long)(row_begin + nrows_local), (long long)ncols_global, (long long)ncols_global);
+
+    SplitCsr sp;
+    split_csr(row_begin, nrows_local, rowptr, colidx, val, sp);
+    c->n_global = ncols_global;
+    c->row_begin = row_begin;
+    c->n_local = nrows_local;
+    c->n_ghost = (int32_t)sp.garray.size();
+    upload_csr(c->Ad, nrows_local, nrows_local, sp.d_rowptr, sp.d_colidx, sp.d_val, true);
+
+    // compress the off-rank block to the rows that have entries
+    std::vector<int32_t> rows, orp(1, 0);
+    for (int32_t r = 0; r < nrows_local; ++r)
+        if (sp.o_rowptr[r + 1] > sp.o_rowptr[r]) {
+            rows.push_back(r);
+            orp.push_back(sp.o_rowptr[r + 1]);
+        }
+    upload_csr(c->Ao, (int32_t)rows.size(), c->n_ghost, orp, sp.o_colidx, sp.o_val, false);
+    c->ao_rows.upload(rows.data(), rows.size(), 8);
+
+    // ---- halo plan (VecScatter of MatMult_MPIAIJ) ----
+    const int P = c->comm->size(), me = c->comm->rank();
+    c->peers.clear();
+    c->send_off.assign(1, 0);
+    c->recv_off.assign(1, 0);
+    std::vector<int32_t> send_idx;
+    if (P > 1) {
+        std::vector<int64_t> mine = {row_begin, row_begin + nrows_local}, all((size_t)2 * P);
+        c->comm->host_allgather(mine.data(), all.data(), 2 * sizeof(int64_t));
+        for (int r = 1; r < P; ++r)
+            if (all[2 * r] != all[2 * r - 1]) fail(SPK_ERR_ARG, "A00: row slabs must tile [0,n) in rank order");
+        std::vector<std::vector<char>> ghosts;
+        c->comm->host_allgatherv(sp.garray.data(), sp.garray.size() * sizeof(int32_t), ghosts);
+        for (int p = 0; p < P; ++p) {
+            if (p == me) continue;
+            // what I receive from p: my ghosts inside p's range (contiguous in sorted garray)
+            const int64_t plo = all[2 * p], phi = all[2 * p + 1];
+            int64_t nrecv = 0;
+            for (int32_t g : sp.garray) nrecv += (g >= plo && g < phi);
+            // what I send to p: p's ghosts inside my range, in p's order
+            const int32_t *pg = (const int32_t *)ghosts[(size_t)p].data();
+            const size_t npg = ghosts[(size_t)p].size() / sizeof(int32_t);
+            int64_t nsend = 0;
+            for (size_t i = 0; i < npg; ++i)
+                if (pg[i] >= row_begin && pg[i] < row_begin + nrows_local) {
+                    send_idx.push_back((int32_t)(pg[i] - row_begin));
+                    ++nsend;
+                }
+            if (nsend == 0 && nrecv == 0) continue;
+            c->peers.push_back(p);
+            c->send_off.push_back(c->send_off.back() + nsend);
+            c->recv_off.push_back(c->recv_off.back() + nrecv);
+        }
+        if (c->recv_off.back() != c->n_ghost) fail(SPK_ERR_ARG, "A00: ghost columns not owned by any rank");
+    } else if (c->n_ghost != 0) {
+        fail(SPK_ERR_ARG, "A00: %d columns fall outside the local rows but there is only one rank", c->n_ghost);
+    }
+    c->send_idx.upload(send_idx.data(), send_idx.size(), 8);
+    c->send_buf.alloc(send_idx.size(), 8);
+    c->xghost.alloc((size_t)c->n_ghost, 8);
+    c->have_A = true;
+    c->pc_ready = false;
+    c->ensure_vectors();
+}
+
+static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32_t *rowptr,
+                        const int32_t *colidx, const double *val)
+{
+    if (!c->have_A) fail(SPK_ERR_STATE, "A10: set SPK_BLOCK_A00 first");
+    if (ncols_global != c->n_global) fail(SPK_ERR_ARG, "A10: %lld columns, A00 has %lld", (long long)ncols_global, (long long)c->n_global);
+    if (m < 0 || m > 8) fail(SPK_ERR_UNSUPPORTED, "A10: m=%d rows; the long-row path supports m <= 8", m);
+    const int32_t nl = c->n_local;
+    const int64_t lo = c->row_begin, hi = lo + nl;
+    // local column numbers, ascending inside each row
+    std::vector<int32_t> col((size_t)rowptr[m]);
+    std::vector<double> v((size_t)rowptr[m]);
+    for (int32_t r = 0; r < m; ++r) {
+        const int32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+        std::vector<int32_t> perm((size_t)(k1 - k0));
+        std::iota(perm.begin(), perm.end(), k0);
+        std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return colidx[a] < colidx[b]; });
+        for (int32_t i = 0; i < k1 - k0; ++i) {
+            const int32_t g = colidx[perm[(size_t)i]];
+            if (g < lo || g >= hi) fail(SPK_ERR_ARG, "A10: column %d not owned by this rank [%lld,%lld)", g, (long long)lo, (long long)hi);
+            col[(size_t)(k0 + i)] = (int32_t)(g - lo);
+            v[(size_t)(k0 + i)] = val[perm[(size_t)i]];
+        }
+    }
+    // column windows
+    WideDev &B = c->B;
+    B.m = m;
+    B.ncols = nl;
+    B.nnz = rowptr[m];
+    int32_t win = 8192;
+    while ((int64_t)(nl + win - 1) / win > k::kMaxBlocks) win *= 2;
+    B.win = win;
+    B.nwin = m > 0 ? (nl + win - 1) / win : 0;
+    std::vector<int32_t> winptr((size_t)(B.nwin + 1) * (size_t)std::max(m, 1));
+    for (int32_t r = 0; r < m; ++r) {
+        const int32_t *b = col.data() + rowptr[r], *e = col.data() + rowptr[r + 1];
+        for (int32_t w = 0; w <= B.nwin; ++w) {
+            const int64_t c0 = (int64_t)w * win;
+            winptr[(size_t)w * m + r] = rowptr[r] + (int32_t)(std::lower_bound(b, e, (int32_t)std::min<int64_t>(c0, nl)) - b);
+        }
+    }
+    B.colidx.upload(col.data(), col.size(), 16);
+    B.val.upload(v.data(), v.size(), 16);
+    B.winptr.upload(winptr.data(), winptr.size(), 8);
+
+    // B^T by rows (n_local x m), entries of a row ordered by constraint index
+    std::vector<int32_t> trp((size_t)nl + 1, 0), tci((size_t)rowptr[m]);
+    std::vector<double> tv((size_t)rowptr[m]);
+    for (int64_t k = 0; k < rowptr[m]; ++k) trp[(size_t)col[(size_t)k] + 1]++;
+    for (int32_t i = 0; i < nl; ++i) trp[(size_t)i + 1] += trp[(size_t)i];
+    std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
+    for (int32_t r = 0; r < m; ++r)
+        for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const int32_t p = fill[(size_t)col[(size_t)k]]++;
+            tci[(size_t)p] = r;
+            tv[(size_t)p] = v[(size_t)k];
+        }
+    upload_csr(c->Bt, nl, m, trp, tci, tv, false);
+    c->m = m;
+    c->have_B = m > 0;
+    c->pc_ready = false;
+    c->ensure_vectors();
+}
+
+void set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
+               const int32_t *rowptr, const int32_t *colidx, const double *val)
+{
+    if (!rowptr || (!colidx && rowptr[nrows_local] > 0) || (!val && rowptr[nrows_local] > 0))
+        fail(SPK_ERR_ARG, "set_block: null array");
+    if (nrows_local < 0) fail(SPK_ERR_ARG, "set_block: negative row count");
+    c->ensure_scratch();
+    if (which == SPK_BLOCK_A00) set_block_A(c, row_begin, nrows_local, ncols_global, rowptr, colidx, val);
+    else if (which == SPK_BLOCK_A10) set_block_B(c, nrows_local, ncols_global, rowptr, colidx, val);
+    else fail(SPK_ERR_ARG, "set_block: unknown block %d", which);
+}
+
+// ---------------------------------------------------------------------------
+// y = K x   (MatMult_Nest over MatMult_MPIAIJ blocks)
+// ---------------------------------------------------------------------------
+void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done)
+{
+    hipStream_t s = c->stream;
+    const int32_t nl = c->n_local, m = c->m;
+    if (c->n_ghost > 0) {
+        k::gather(x, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
+        c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
+    }
+    k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
+    if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, y, done, s);
+    if (m > 0) {
+        k::wide_dot(c->B, x, c->partials.p, done, s);
+        k::reduce_partials(c->partials.p, c->B.nwin, k::kPartialLd, m, y + nl, done, s);
+        c->comm->allreduce_sum(y + nl, m, s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// KSPSetUp / PCSetUp: diag(A)^-1, S^ = diag(B diag(A)^-1 B^T)
+// ---------------------------------------------------------------------------
+void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
+{
+    if (!c->have_A) fail(SPK_ERR_STATE, "pc_setup: no A00 block");
+    if (pc_type < SPK_PC_NONE || pc_type > SPK_PC_SCHUR) fail(SPK_ERR_ARG, "pc_setup: unknown pc_type %d", pc_type);
+    if (pc_type == SPK_PC_SCHUR && !c->have_B) fail(SPK_ERR_STATE, "pc_setup: Schur fieldsplit needs the A10 block");
+    if (schur_fact < SPK_SCHUR_DIAG || schur_fact > SPK_SCHUR_FULL) fail(SPK_ERR_ARG, "pc_setup: unknown schur_fact %d", schur_fact);
+    hipStream_t s = c->stream;
+    c->ensure_scratch();
+    c->ensure_vectors();
+    c->dinv.alloc((size_t)c->n_local, 8);
+    k::extract_diag_inv(c->Ad, c->dinv.p, s);
+    const int m = c->m;
+    if (m > 0) {
+        c->gram.alloc((size_t)m * m);
+        c->shat.alloc((size_t)m);
+        // row r of B .* dinv scattered densely, then B * that = G[r, :]
+        SPK_HIP(hipMemsetAsync(c->tmp.p, 0, sizeof(double) * (size_t)c->ld, s));
+        std::vector<int32_t> wp((size_t)(c->B.nwin + 1) * m);
+        SPK_HIP(hipMemcpy(wp.data(), c->B.winptr.p, wp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int r = 0; r < m; ++r) {
+            const int k0 = wp[(size_t)r], k1 = wp[(size_t)c->B.nwin * m + r];
+            k::scatter_row(c->B.colidx.p, c->B.val.p, k0, k1, c->dinv.p, c->tmp.p, s);
+            k::wide_dot(c->B, c->tmp.p, c->partials.p, nullptr, s);
+            k::reduce_partials(c->partials.p, c->B.nwin, k::kPartialLd, m, c->gram.p + (size_t)r * m, nullptr, s);
+            k::scatter_row(c->B.colidx.p, c->B.val.p, k0, k1, nullptr, c->tmp.p, s);
+        }
+        c->comm->allreduce_sum(c->gram.p, m * m, s);
+        SPK_HIP(hipStreamSynchronize(s));
+        std::vector<double> G((size_t)m * m), sh((size_t)m);
+        SPK_HIP(hipMemcpy(G.data(), c->gram.p, G.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int r = 0; r < m; ++r) sh[(size_t)r] = G[(size_t)r * m + r];
+        SPK_HIP(hipMemcpy(c->shat.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    SPK_HIP(hipStreamSynchronize(s));
+    c->pc_type = pc_type;
+    c->schur_fact = schur_fact;
+    c->pc_ready = true;
+}
+
+// ---------------------------------------------------------------------------
+// y = M^-1 x   (PCApply_Jacobi / PCApply_FieldSplit_Schur)
+// ---------------------------------------------------------------------------
+void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
+{
+    hipStream_t s = c->stream;
+    const int32_t nl = c->n_local, m = c->m;
+    const double *x0 = x, *x1 = x + nl;
+    double *y0 = y, *y1 = y + nl;
+    if (c->pc_type == SPK_PC_NONE) {
+        k::axpby(1.0, x, 0.0, y, (int64_t)nl + m, done, s);
+        return;
+    }
+    if (c->pc_type == SPK_PC_JACOBI) {
+        k::jacobi(c->dinv.p, x0, y0, nl, done, s);
+        k::copy_small(x1, y1, m, done, s);  // zero diagonal of the (1,1) block -> 1
+        return;
+    }
+    switch (c->schur_fact) {
+    case SPK_SCHUR_DIAG:
+        k::jacobi(c->dinv.p, x0, y0, nl, done, s);
+        k::schur_y1(SPK_SCHUR_DIAG, m, x1, nullptr, c->shat.p, y1, done, s);
+        break;
+    case SPK_SCHUR_UPPER:
+        k::schur_y1(SPK_SCHUR_UPPER, m, x1, nullptr, c->shat.p, y1, done, s);
+        k::bt_update(0, c->Bt, c->dinv.p, x0, y1, y0, done, s);
+        break;
+    case SPK_SCHUR_LOWER:
+    default:  // FULL
+        // t = B (D x0) without storing D x0
+        k::wide_dot_jacobi(c->B, x0, c->dinv.p, c->partials.p, done, s);
+        k::reduce_partials(c->partials.p, c->B.nwin, k::kPartialLd, m, c->ttmp.p, done, s);
+        c->comm->allreduce_sum(c->ttmp.p, m, s);
+        k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
+        if (c->schur_fact == SPK_SCHUR_LOWER) k::jacobi(c->dinv.p, x0, y0, nl, done, s);
+        else k::bt_update(1, c->Bt, c->dinv.p, x0, y1, y0, done, s);
+        break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// KSPSolve_FGMRES, device resident
+// ---------------------------------------------------------------------------
+static void ensure_krylov(spk_ctx *c, const spk_opts &o)
+{
+    c->ensure_scratch();
+    c->ensure_vectors();
+    const int mk = o.restart;
+    if (mk < 1 || mk > k::kMaxNv - 2) fail(SPK_ERR_ARG, "fgmres: restart %d outside [1,%d]", mk, k::kMaxNv - 2);
+    const int32_t hist_cap = (int32_t)std::min<int64_t>((int64_t)std::max(o.max_it, 0) + 2, 1 << 22);
+    if (c->ws_restart != mk) {
+        c->V.alloc((size_t)c->ld * (mk + 1));
+        c->Z.alloc((size_t)c->ld * mk);
+        c->ws_restart = mk;
+    }
+    const int ldh = mk + 2;
+    const size_t nd = (size_t)ldh * (mk + 1) + 4 * (size_t)(mk + 2) + (size_t)hist_cap + 64;
+    if (c->kry_d.n < nd) c->kry_d.alloc(nd);
+    if (!c->kst.p) c->kst.alloc(1);
+    double *p = c->kry_d.p;
+    c->ka.st = c->kst.p;
+    c->ka.ldh = ldh;
+    c->ka.H = p;      p += (size_t)ldh * (mk + 1);
+    c->ka.cc = p;     p += mk + 2;
+    c->ka.ss = p;     p += mk + 2;
+    c->ka.rs = p;     p += mk + 2;
+    c->ka.nrs = p;    p += mk + 2;
+    c->ka.hcol = nullptr;
+    c->ka.hist = p;
+    c->ka.hist_cap = hist_cap;
+}
+
+void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_result *res, double *history,
+            int32_t history_cap)
+{
+    if (!c->have_A) fail(SPK_ERR_STATE, "fgmres: no operator");
+    if (!c->pc_ready) fail(SPK_ERR_STATE, "fgmres: call spk_pc_setup first (KSPSetUp)");
+    if (o.orthog != SPK_ORTHOG_CGS) fail(SPK_ERR_UNSUPPORTED, "fgmres: only classical Gram-Schmidt is implemented");
+    ensure_krylov(c, o);
+    hipStream_t s = c->stream;
+    const int mk = o.restart;
+    const int64_t N = (int64_t)c->n_local + c->m, ld = c->ld;
+    const int64_t n_dot = (int64_t)c->n_local + (c->comm->rank() == 0 ? c->m : 0);
+    const int32_t *done = &c->kst.p->done;
+    const int32_t *loc_done = &c->kst.p->loc_done;
+    const double *inv_tt = &c->kst.p->inv_tt;
+    double *sm = c->small.p;  // [0..63] dots (+w.w), [64] norm^2, [128] ||b||^2
+    double *V = c->V.p, *Z = c->Z.p;
+    int nb = 0;
+    auto Vj = [&](int j) { return V + (size_t)ld * j; };
+    auto Zj = [&](int j) { return Z + (size_t)ld * j; };
+
+    SPK_HIP(hipStreamSynchronize(s));
+    const auto t0 = std::chrono::steady_clock::now();
+
+    // ||b|| for KSPConvergedDefault
+    k::sqnorm(b, n_dot, c->partials.p, &nb, nullptr, s);
+    k::reduce_partials(c->partials.p, nb, k::kPartialLd, 1, sm + 128, nullptr, s);
+    c->comm->allreduce_sum(sm + 128, 1, s);
+    k::krylov_init(c->ka, o, sm + 128, s);
+
+    // initial residual into V0
+    if (!o.guess_nonzero) {
+        SPK_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)N, s));
+        SPK_HIP(hipMemcpyAsync(Vj(0), b, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
+    } else {
+        op_mult(c, x, c->tmp.p, nullptr);
+        SPK_HIP(hipMemcpyAsync(Vj(0), b, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, s));
+        k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, nullptr, s);
+    }
+
+    KrylovState st{};
+    int cycles = 0;
+    for (;;) {
+        // ---- cycle start: ||r||, convergence test, v0 = r/||r|| ----
+        k::sqnorm(Vj(0), n_dot, c->partials.p, &nb, done, s);
+        k::reduce_partials(c->partials.p, nb, k::kPartialLd, 1, sm + 64, done, s);
+        c->comm->allreduce_sum(sm + 64, 1, s);
+        k::krylov_cycle_begin(c->ka, sm + 64, s);
+        k::scale_dev(Vj(0), N, inv_tt, done, s);
+
+        bool stop = false;
+        for (int loc = 0; loc < mk && !stop; ++loc) {
+            double *w = Vj(loc + 1);
+            op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
+            op_mult(c, Zj(loc), w, done);            // w = K z_j
+            // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 in the same pass)
+            k::mdot(V, ld, loc + 1, w, N, n_dot, c->partials.p, &nb, done, s);
+            k::reduce_partials(c->partials.p, nb, k::kPartialLd, loc + 2, sm, done, s);
+            c->comm->allreduce_sum(sm, loc + 2, s);
+            k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->partials.p, &nb, done, s);
+            k::reduce_partials(c->partials.p, nb, k::kPartialLd, 1, sm + 64, done, s);
+            c->comm->allreduce_sum(sm + 64, 1, s);
+            // Hessenberg column, Givens, convergence -- on the device
+            k::krylov_givens(c->ka, loc, sm, sm + 64, s);
+            k::scale_dev(w, N, inv_tt, done, s);  // v_{j+1} = w / ||w||
+            if (o.check_every > 0 && (loc + 1) % o.check_every == 0 && loc + 1 < mk) {
+                SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
+                SPK_HIP(hipStreamSynchronize(s));
+                stop = st.done != 0;
+            }
+        }
+        // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
+        k::krylov_cycle_end(c->ka, s);
+        k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->partials.p, &nb, nullptr, s);
+        // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
+        op_mult(c, x, c->tmp.p, done);
+        k::axpby(1.0, b, 0.0, Vj(0), N, done, s);
+        k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, done, s);
+        ++cycles;
+        SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        if (st.done) break;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+
+    res->its = st.its;
+    res->reason = st.reason;
+    res->rnorm = st.rnorm;
+    res->rnorm0 = st.rnorm0;
+    res->cycles = cycles;
+    res->solve_seconds = std::chrono::duration<double>(t1 - t0).count();
+    int32_t nh = std::min<int32_t>(st.its + 1, c->ka.hist_cap);
+    if (!history) nh = 0;
+    nh = std::min(nh, history_cap);
+    if (nh > 0) SPK_HIP(hipMemcpy(history, c->ka.hist, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost));
+    res->hist_len = nh;
+}
+
+}  // namespace spk

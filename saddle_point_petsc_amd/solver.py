@@ -1,0 +1,248 @@
+"""Thin object wrappers over the C ABI (include/spk.h) and the KSP facade
+(include/spk_ksp.h).  `KSP` mirrors the reference's call site
+/root/reference/src/SaddlePointProblem.c:65-72 (petsc4py-style method names)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, Opts, Result, MatCSR, SpkError
+
+PC_NONE, PC_JACOBI, PC_SCHUR = 0, 1, 2
+SCHUR_DIAG, SCHUR_LOWER, SCHUR_UPPER, SCHUR_FULL = 0, 1, 2, 3
+BLOCK_A00, BLOCK_A10 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib.spk_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k}")
+        setattr(o, k, v)
+    return o
+
+
+def unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib.spk_comm_unique_id(buf)
+    if rc != 0:
+        raise SpkError(rc, lib.spk_last_error(None).decode())
+    return buf.raw
+
+
+class LocalGroup:
+    """In-process logical ranks on one device (parity tests only)."""
+
+    def __init__(self, nranks):
+        self.h = C.c_void_p()
+        rc = lib.spk_local_group_create(C.byref(self.h), nranks)
+        if rc != 0:
+            raise SpkError(rc, "spk_local_group_create")
+        self.nranks = nranks
+
+    def close(self):
+        if self.h:
+            lib.spk_local_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Context:
+    """One solver context (= one KSP) on one GPU."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib.spk_create(C.byref(self.h), device)
+        if rc != 0:
+            raise SpkError(rc, lib.spk_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SpkError(rc, lib.spk_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            lib.spk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def comm_init_rccl(self, rank, nranks, id128):
+        self._chk(lib.spk_comm_init_rccl(self.h, rank, nranks, id128))
+
+    def comm_init_local(self, group, rank):
+        self._chk(lib.spk_comm_init_local(self.h, group.h, rank))
+
+    def set_block(self, which, A):
+        nrows = A.nrows
+        self._chk(lib.spk_set_block(self.h, which, A.row_begin if which == BLOCK_A00 else 0, nrows,
+                                    A.ncols, A.rowptr, A.colidx, A.val))
+
+    def pc_setup(self, pc_type, schur_fact=SCHUR_FULL):
+        self._chk(lib.spk_pc_setup(self.h, pc_type, schur_fact))
+
+    def sizes(self):
+        ng, nl, m, nnz, gh = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+        lib.spk_get_sizes(self.h, C.byref(ng), C.byref(nl), C.byref(m), C.byref(nnz), C.byref(gh))
+        return dict(n_global=ng.value, n_local=nl.value, m=m.value, nnz_local=nnz.value, n_ghost=gh.value)
+
+    def _n(self):
+        s = self.sizes()
+        return s["n_local"] + s["m"]
+
+    def schur_diag(self):
+        out = np.zeros(self.sizes()["m"])
+        self._chk(lib.spk_get_schur_diag(self.h, out))
+        return out
+
+    def jacobi_diag(self):
+        out = np.zeros(self.sizes()["n_local"])
+        self._chk(lib.spk_get_jacobi_diag(self.h, out))
+        return out
+
+    def mult(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        assert x.shape == (self._n(),)
+        y = np.zeros_like(x)
+        self._chk(lib.spk_mult(self.h, x, y, MEM_HOST))
+        return y
+
+    def pc_apply(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        assert x.shape == (self._n(),)
+        y = np.zeros_like(x)
+        self._chk(lib.spk_pc_apply(self.h, x, y, MEM_HOST))
+        return y
+
+    def fgmres(self, b, x0=None, **kw):
+        b = np.ascontiguousarray(b, np.float64)
+        assert b.shape == (self._n(),)
+        o = default_opts(**kw)
+        x = np.zeros_like(b)
+        if x0 is not None:
+            x[:] = x0
+            o.guess_nonzero = 1
+        res = Result()
+        cap = int(min(o.max_it + 2, 1 << 22))
+        hist = np.zeros(cap)
+        self._chk(lib.spk_fgmres(self.h, b, x, MEM_HOST, C.byref(o), C.byref(res), hist.ctypes.data, cap))
+        return x, dict(its=res.its, reason=res.reason, rnorm=res.rnorm, rnorm0=res.rnorm0,
+                       cycles=res.cycles, solve_seconds=res.solve_seconds,
+                       history=hist[:res.hist_len].copy())
+
+    def mdot(self, V, w):
+        V = np.ascontiguousarray(V, np.float64)
+        w = np.ascontiguousarray(w, np.float64)
+        nv, n = V.shape
+        h = np.zeros(nv + 1)
+        self._chk(lib.spk_kernel_mdot(self.h, n, nv, V.reshape(-1), n, w, h))
+        return h[:nv], h[nv]
+
+    def maxpy(self, a, V, w):
+        V = np.ascontiguousarray(V, np.float64)
+        a = np.ascontiguousarray(a, np.float64)
+        w = np.array(w, np.float64)
+        nv, n = V.shape
+        nrm2 = C.c_double()
+        self._chk(lib.spk_kernel_maxpy(self.h, n, nv, a, V.reshape(-1), n, w, C.byref(nrm2)))
+        return w, nrm2.value
+
+    def time_spmv(self, warmup=5, reps=50):
+        ms = C.c_double()
+        self._chk(lib.spk_time_spmv(self.h, warmup, reps, C.byref(ms)))
+        return ms.value
+
+
+def _mat(A):
+    m = MatCSR()
+    m.row_begin, m.nrows_local, m.ncols_global = A.row_begin, A.nrows, A.ncols
+    m.rowptr, m.colidx, m.val = A.rowptr.ctypes.data, A.colidx.ctypes.data, A.val.ctypes.data
+    return m
+
+
+class KSP:
+    """Mirror of the reference's solver object: create / setOperators /
+    setFromOptions / setUp / solve / destroy (SaddlePointProblem.c:65-72)."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib.SpkKSPCreate(device, C.byref(self.h))
+        if rc != 0:
+            msg = lib.SpkKSPGetError(self.h).decode() if self.h else "SpkKSPCreate failed"
+            lib.SpkKSPDestroy(C.byref(self.h))
+            raise SpkError(rc, msg)
+        self._keep = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SpkError(rc, lib.SpkKSPGetError(self.h).decode())
+
+    def setCommRCCL(self, rank, nranks, id128):
+        self._chk(lib.SpkKSPSetCommRCCL(self.h, rank, nranks, id128))
+
+    def setOperators(self, A, B=None):
+        a = _mat(A)
+        b = _mat(B) if B is not None else None
+        self._chk(lib.SpkKSPSetOperators(self.h, C.byref(a), C.byref(b) if b is not None else None))
+        self._n = A.nrows + (B.nrows if B is not None else 0)
+
+    def setFromOptions(self, options):
+        """options: PETSc-style string or list, e.g. '-ksp_type fgmres -ksp_rtol 1e-8'."""
+        args = options.split() if isinstance(options, str) else list(options)
+        arr = (C.c_char_p * max(len(args), 1))(*[a.encode() for a in args])
+        self._chk(lib.SpkKSPSetFromOptions(self.h, len(args), arr))
+
+    def setUp(self):
+        self._chk(lib.SpkKSPSetUp(self.h))
+
+    def solve(self, b, x=None):
+        b = np.ascontiguousarray(b, np.float64)
+        assert b.shape == (self._n,)
+        x = np.zeros_like(b) if x is None else x
+        self._chk(lib.SpkKSPSolve(self.h, b, x))
+        return x
+
+    def getIterationNumber(self):
+        v = C.c_int32()
+        lib.SpkKSPGetIterationNumber(self.h, C.byref(v))
+        return v.value
+
+    def getConvergedReason(self):
+        v = C.c_int32()
+        lib.SpkKSPGetConvergedReason(self.h, C.byref(v))
+        return v.value
+
+    def getResidualNorm(self):
+        v = C.c_double()
+        lib.SpkKSPGetResidualNorm(self.h, C.byref(v))
+        return v.value
+
+    def getSolveTime(self):
+        v = C.c_double()
+        lib.SpkKSPGetSolveTime(self.h, C.byref(v))
+        return v.value
+
+    def getConvergenceHistory(self):
+        p, n = C.POINTER(C.c_double)(), C.c_int32()
+        lib.SpkKSPGetResidualHistory(self.h, C.byref(p), C.byref(n))
+        return np.array([p[i] for i in range(n.value)])
+
+    def getOptions(self):
+        o, pc, sf = Opts(), C.c_int32(), C.c_int32()
+        lib.SpkKSPGetOptions(self.h, C.byref(o), C.byref(pc), C.byref(sf))
+        return o, pc.value, sf.value
+
+    def destroy(self):
+        if self.h:
+            lib.SpkKSPDestroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.destroy()

@@ -1,0 +1,353 @@
+"""Parity of the HIP path (through the C ABI of libspk.so) against the CPU
+oracle on the same inputs.  Needs a real MI355X: run with -m gpu.
+
+Tolerances (FP64, stated per SURVEY.md section 8(c)):
+  kernel parity    <= 1e-13 relative (summation order only); the A-block SpMV is
+                   checked for BITWISE equality, its sums run in CSR order
+  solution parity  <= 1e-8 relative when both solves run to rtol 1e-10
+  iteration parity same count +-1, residual history within 1e-6 relative
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def ctx(spk):
+    c = spk.Context(0)
+    yield c
+    c.close()
+
+
+def _x(n, seed=12345):
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, n)
+
+
+# --------------------------------------------------------------------------- SpMV
+@pytest.mark.parametrize("mx,my", [(4, 4), (32, 32), (33, 33), (64, 64), (50, 7), (256, 256)])
+def test_spmv_A_block_bitwise(spk, oracle, mx, my):
+    A, _ = spk.AssembleOperator_Laplace(mx, my)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        for seed in (1, 2):
+            x = _x(A.nrows, seed)
+            y = c.mult(x)
+            y_ref = oracle.spmv(A, x)
+            assert np.array_equal(y, y_ref), f"max diff {np.abs(y - y_ref).max()}"
+
+
+def test_spmv_irregular_rows(spk, oracle):
+    """Ragged CSR: empty rows, rows longer than one LDS tile (long-row path),
+    unsorted columns, tile boundaries at odd offsets."""
+    rng = np.random.default_rng(7)
+    n = 3000
+    lens = rng.integers(0, 40, n)
+    lens[5] = 0; lens[6] = 0; lens[100] = 5000; lens[101] = 4097; lens[2999] = 1
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    colidx = rng.integers(0, n, rowptr[-1]).astype(np.int32)
+    val = rng.standard_normal(rowptr[-1])
+    A = spk.CSR(rowptr, colidx, val, n)
+    x = _x(n)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        y = c.mult(x)
+    y_ref = oracle.spmv(A, x)
+    short = lens <= 4096
+    assert np.array_equal(y[short], y_ref[short])                      # CSR-order sums: bitwise
+    assert np.allclose(y[~short], y_ref[~short], rtol=1e-12, atol=1e-12)  # long rows: tree order
+
+
+def test_spmv_full_size_1024(spk, oracle):
+    """BASELINE config grid 1024 x 1024 (2.1 M rows, 37.7 M stored non-zeros)."""
+    A, _ = spk.AssembleOperator_Laplace(1024)
+    x = np.sin(0.37 * np.arange(A.nrows))
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        y = c.mult(x)
+        # linearity: A(2x + e) = 2 A x + A e
+        e = _x(A.nrows, 3)
+        assert relerr(c.mult(2 * x + e), 2 * y + c.mult(e)) < 1e-14
+    assert np.array_equal(y, oracle.spmv(A, x))
+
+
+# --------------------------------------------------------------------------- nest operator, preconditioners
+@pytest.mark.parametrize("mx,my", [(5, 5), (32, 32), (40, 23)])
+def test_nest_mult_and_all_preconditioners(spk, oracle, mx, my):
+    A, _ = spk.AssembleOperator_Laplace(mx, my)
+    B, _ = spk.AssembleOperator_Constraints(mx, my)
+    x = _x(A.nrows + 4)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        assert relerr(c.mult(x), oracle.apply_K(A, B, x)) < KERNEL_TOL
+        c.pc_setup(spk.PC_JACOBI)
+        assert np.array_equal(c.jacobi_diag(), oracle.jacobi_dinv(A))
+        assert relerr(c.pc_apply(x), oracle.pc_apply(A, B, oracle.PC_JACOBI, 0, x)) < KERNEL_TOL
+        c.pc_setup(spk.PC_NONE)
+        assert np.array_equal(c.pc_apply(x), x)
+        for fact in range(4):
+            c.pc_setup(spk.PC_SCHUR, fact)
+            assert relerr(c.schur_diag(), oracle.schur_setup(A, B)[0]) < KERNEL_TOL
+            assert relerr(c.pc_apply(x), oracle.pc_apply(A, B, oracle.PC_SCHUR, fact, x)) < KERNEL_TOL
+
+
+def test_schur_diag_known_answer(spk, appendix_b):
+    A, _ = spk.AssembleOperator_Laplace(32)
+    B, _ = spk.AssembleOperator_Constraints(32)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        assert np.allclose(c.schur_diag(), appendix_b["constraints_m32"]["shat"], rtol=1e-8)
+
+
+# --------------------------------------------------------------------------- Gram-Schmidt kernels
+@pytest.mark.parametrize("n,nv", [(1, 1), (7, 3), (2047, 8), (2048, 9), (4099, 17), (100000, 31), (300001, 40), (65536, 0)])
+def test_mdot_maxpy(ctx, n, nv):
+    rng = np.random.default_rng(n + nv)
+    V = rng.standard_normal((max(nv, 1), n))[:nv]
+    w = rng.standard_normal(n)
+    h, ww = ctx.mdot(V.reshape(nv, n), w)
+    assert np.allclose(h, V @ w, rtol=1e-12, atol=1e-12 * np.sqrt(n))
+    assert ww == pytest.approx(w @ w, rel=1e-13)
+    a = rng.standard_normal(nv)
+    w2, nrm2 = ctx.maxpy(a, V.reshape(nv, n), w)
+    ref = w + a @ V if nv else w
+    assert relerr(w2, ref) < KERNEL_TOL
+    assert nrm2 == pytest.approx(ref @ ref, rel=1e-13)
+
+
+# --------------------------------------------------------------------------- FGMRES
+def _solve_both(spk, oracle, A, B, rhs, pc, fact=3, **kw):
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        if B is not None:
+            c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(pc, fact)
+        x, info = c.fgmres(rhs, **kw)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=pc, schur_fact=fact, **kw)
+    return x, info, xo, io
+
+
+def _check_iteration_parity(info, io):
+    assert info["reason"] == io["reason"]
+    assert abs(info["its"] - io["its"]) <= 1
+    k = min(len(info["history"]), len(io["history"]))
+    assert np.allclose(info["history"][:k], io["history"][:k], rtol=1e-6)
+
+
+def test_fgmres_jacobi_matches_oracle_and_fixture(spk, oracle, golden_m32):
+    A, f = spk.AssembleOperator_Laplace(32)
+    x, info, xo, io = _solve_both(spk, oracle, A, None, f, spk.PC_JACOBI, rtol=1e-5)
+    _check_iteration_parity(info, io)
+    assert info["its"] == 75 and info["reason"] == 2
+    assert np.allclose(info["history"], golden_m32["jacobi_hist"], rtol=1e-6)
+    assert relerr(x, xo) < 1e-8
+
+
+@pytest.mark.parametrize("fact", [0, 1, 2, 3])
+def test_fgmres_saddle_schur(spk, oracle, golden_m32, fact):
+    A, f = spk.AssembleOperator_Laplace(32)
+    B, g = spk.AssembleOperator_Constraints(32)
+    rhs = np.concatenate([f, g])
+    x, info, xo, io = _solve_both(spk, oracle, A, B, rhs, spk.PC_SCHUR, fact, rtol=1e-10)
+    _check_iteration_parity(info, io)
+    assert relerr(x, xo) < 1e-8
+    assert relerr(x, golden_m32["saddle"]) < 1e-8                       # scipy sparse LU
+    assert np.allclose(x[-4:], golden_m32["saddle"][-4:], rtol=1e-7)
+
+
+def test_fgmres_rtol_1e8_iteration_counts(spk, golden_m32):
+    A, f = spk.AssembleOperator_Laplace(32)
+    B, g = spk.AssembleOperator_Constraints(32)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        for fact in range(4):
+            c.pc_setup(spk.PC_SCHUR, fact)
+            _, info = c.fgmres(rhs, rtol=1e-8)
+            assert abs(info["its"] - golden_m32["schur_its"][fact]) <= 1 and info["reason"] == 2
+
+
+def test_fgmres_host_check_cadence_does_not_change_the_iterate(spk):
+    A, f = spk.AssembleOperator_Laplace(24)
+    B, g = spk.AssembleOperator_Constraints(24)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x0, i0 = c.fgmres(rhs, rtol=1e-9, check_every=0)
+        x1, i1 = c.fgmres(rhs, rtol=1e-9, check_every=1)
+        x7, i7 = c.fgmres(rhs, rtol=1e-9, check_every=7)
+    assert i0["its"] == i1["its"] == i7["its"] and i0["reason"] == 2
+    assert np.array_equal(x0, x1) and np.array_equal(x0, x7)           # deterministic, bit for bit
+    assert np.array_equal(i0["history"], i1["history"])
+
+
+def test_fgmres_edge_cases(spk, oracle):
+    A, f = spk.AssembleOperator_Laplace(9)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.pc_setup(spk.PC_JACOBI)
+        x, info = c.fgmres(np.zeros_like(f))
+        assert info["its"] == 0 and info["reason"] == 3 and not x.any()
+        c.pc_setup(spk.PC_NONE)
+        x, info = c.fgmres(f, max_it=3, rtol=1e-14)
+        xo, io = oracle.fgmres(A, f, pc_type=oracle.PC_NONE, max_it=3, rtol=1e-14)
+        assert info["its"] == 3 and info["reason"] == -3 and relerr(x, xo) < 1e-10
+        x, info = c.fgmres(f, max_it=0)
+        assert info["its"] == 0 and info["reason"] == -3
+        c.pc_setup(spk.PC_JACOBI)
+        x, info = c.fgmres(f, restart=5, rtol=1e-10)
+        xo, io = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, restart=5, rtol=1e-10)
+        assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 1 and relerr(x, xo) < 1e-8
+        assert info["cycles"] >= 2
+        # non-zero initial guess
+        x, info = c.fgmres(f, x0=xo, rtol=1e-8)
+        assert info["its"] == 0 and info["reason"] in (2, 3)
+        x, info = c.fgmres(f, x0=0.5 * xo, rtol=1e-9)
+        xo2, io2 = oracle.fgmres(A, f, x0=0.5 * xo, pc_type=oracle.PC_JACOBI, rtol=1e-9)
+        assert abs(info["its"] - io2["its"]) <= 1 and relerr(x, xo2) < 1e-8
+        b = f.copy(); b[3] = np.nan
+        x, info = c.fgmres(b)
+        assert info["reason"] == -9
+
+
+def test_fgmres_config3_512_truncated(spk, oracle):
+    """BASELINE config 3 (512 x 512, full Schur path): 45 iterations of both
+    implementations must agree (the oracle finishes this in seconds)."""
+    A, f = spk.AssembleOperator_Laplace(512)
+    B, g = spk.AssembleOperator_Constraints(512)
+    rhs = np.concatenate([f, g])
+    x, info, xo, io = _solve_both(spk, oracle, A, B, rhs, spk.PC_SCHUR, 3, rtol=1e-30, max_it=45)
+    assert info["its"] == io["its"] == 45 and info["reason"] == io["reason"] == -3
+    assert np.allclose(info["history"], io["history"], rtol=1e-8)
+    assert relerr(x, xo) < 1e-9
+
+
+def test_error_reporting(spk):
+    A, f = spk.AssembleOperator_Laplace(8)
+    with spk.Context(0) as c:
+        with pytest.raises(spk.SpkError, match="operator"):
+            c.mult(np.zeros(0))
+        c.set_block(spk.BLOCK_A00, A)
+        with pytest.raises(spk.SpkError, match="pc_setup"):
+            c.fgmres(f)
+        with pytest.raises(spk.SpkError, match="A10"):
+            c.pc_setup(spk.PC_SCHUR)
+        bad = spk.CSR(A.rowptr, A.colidx + 1, A.val, A.ncols)
+        with pytest.raises(spk.SpkError, match="out of range"):
+            c.set_block(spk.BLOCK_A00, bad)
+        c.pc_setup(spk.PC_JACOBI)
+        with pytest.raises(spk.SpkError, match="restart"):
+            c.fgmres(f, restart=0)
+
+
+# --------------------------------------------------------------------------- the reference's call sequence
+def test_ksp_call_sequence_like_the_reference(spk, oracle, golden_m32):
+    """KSPCreate / SetOperators / SetFromOptions / SetUp / Solve / Destroy
+    (SaddlePointProblem.c:65-72) with the finished nest and the options of
+    SURVEY.md Appendix C."""
+    A, f = spk.AssembleOperator_Laplace(32)
+    B, g = spk.AssembleOperator_Constraints(32)
+    ksp = spk.KSP()
+    ksp.setOperators(A, B)
+    ksp.setFromOptions("-ksp_type fgmres -ksp_rtol 1e-8 -pc_type fieldsplit -pc_fieldsplit_type schur "
+                       "-pc_fieldsplit_schur_fact_type full -pc_fieldsplit_schur_precondition selfp "
+                       "-fieldsplit_0_ksp_type preonly -fieldsplit_0_pc_type jacobi "
+                       "-fieldsplit_1_ksp_type preonly -fieldsplit_1_pc_type jacobi")
+    ksp.setUp()
+    x = ksp.solve(np.concatenate([f, g]))
+    assert ksp.getConvergedReason() == 2
+    assert abs(ksp.getIterationNumber() - golden_m32["schur_its"][3]) <= 1
+    assert relerr(x, golden_m32["saddle"]) < 1e-6
+    assert len(ksp.getConvergenceHistory()) == ksp.getIterationNumber() + 1
+    # as written in the reference: A alone, options decide the rest
+    ksp2 = spk.KSP()
+    ksp2.setOperators(A)
+    ksp2.setFromOptions("-ksp_type fgmres -pc_type jacobi")
+    u = ksp2.solve(f)                                   # KSPSolve sets up on demand
+    assert ksp2.getIterationNumber() == 75 and relerr(u, golden_m32["u"]) < 1e-4
+    ksp.destroy(); ksp2.destroy()
+
+
+# --------------------------------------------------------------------------- partitioned algorithm on one GPU
+def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, **kw):
+    import threading
+    grp = spk.LocalGroup(P)
+    out, errs = [None] * P, []
+    n = 2 * mx * my
+
+    def work(r):
+        try:
+            b, e = spk.partition_slab(mx, my, r, P)
+            A, _ = spk.AssembleOperator_Laplace(mx, my, b, e)
+            c = spk.Context(0)
+            c.comm_init_local(grp, r)
+            c.set_block(spk.BLOCK_A00, A)
+            if with_B:
+                Bs, _ = spk.AssembleOperator_Constraints(mx, my, b, e)
+                c.set_block(spk.BLOCK_A10, Bs)
+            c.pc_setup(pc, fact)
+            rhs = np.concatenate([rhs_full[b:e], rhs_full[n:]])
+            y = c.mult(rhs)
+            z = c.pc_apply(rhs)
+            x, info = c.fgmres(rhs, **kw)
+            out[r] = (b, e, y, z, x, info, c.sizes())
+            c.close()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            raise
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    grp.close()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_row_partitioned_solver_matches_single_rank(spk, oracle, P):
+    mx, my = 24, 26
+    A, f = spk.AssembleOperator_Laplace(mx, my)
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    rhs = np.concatenate([f, g])
+    n = A.nrows
+    out = _run_ranks(spk, P, mx, my, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=1e-10)
+    y_ref = oracle.apply_K(A, B, rhs)
+    z_ref = oracle.pc_apply(A, B, oracle.PC_SCHUR, 3, rhs)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10)
+    y = np.zeros(n + 4); z = np.zeros(n + 4); x = np.zeros(n + 4)
+    for (b, e, yr, zr, xr, info, sz) in out:
+        y[b:e], z[b:e], x[b:e] = yr[:-4], zr[:-4], xr[:-4]
+        y[n:], z[n:], x[n:] = yr[-4:], zr[-4:], xr[-4:]
+        assert sz["n_ghost"] == 2 * mx * ((b > 0) + (e < n))           # one node line per neighbour
+        assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 1
+        assert np.array_equal(xr[-4:], out[0][4][-4:])                   # multipliers replicated bit for bit
+        assert np.array_equal(info["history"], out[0][5]["history"])     # every rank takes the same branch
+    assert relerr(y, y_ref) < KERNEL_TOL and relerr(z, z_ref) < KERNEL_TOL
+    assert relerr(x, xo) < 1e-8
+
+
+def test_rccl_single_rank_communicator(spk, oracle):
+    """RCCL path with nranks = 1 (all a 1-GPU box can run): unique id, init,
+    in-stream all-reduce of the Krylov scalars."""
+    A, f = spk.AssembleOperator_Laplace(16)
+    B, g = spk.AssembleOperator_Constraints(16)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.comm_init_rccl(0, 1, spk.unique_id())
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x, info = c.fgmres(rhs, rtol=1e-10)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10)
+    assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 1 and relerr(x, xo) < 1e-8

@@ -1,0 +1,193 @@
+"""Host-side logic of the product that needs no GPU: the C-ABI library loads
+and exports every declared symbol, the assembler equals the oracle bit for bit,
+the partition/halo split, the option parser.  CPU only (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:spk_|Spk)\w+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("header", ["spk.h", "spk_ksp.h", "spk_assembly.h"])
+def test_library_exports_every_declared_symbol(spk, header):
+    names = _declared_functions(header)
+    assert len(names) >= 8
+    L = C.CDLL(spk.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"{header}: not exported by libspk.so: {missing}"
+
+
+def test_version_and_defaults(spk):
+    assert spk.lib.spk_version() == 100
+    o = spk.default_opts()
+    # PETSc defaults
+    assert (o.restart, o.max_it, o.rtol, o.abstol, o.dtol, o.guess_nonzero) == (30, 10000, 1e-5, 1e-50, 1e4, 0)
+
+
+def test_no_cpu_fallback(spk):
+    """Without a GPU the product refuses to create a context; it never computes on the CPU."""
+    import subprocess, sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import saddle_point_petsc_amd as S\n"
+            "n = C.c_int(); \n"
+            "try:\n S.Context(0); print('CREATED')\nexcept S.SpkError as e:\n print('REFUSED', e)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "REFUSED" in out and "no CPU fallback" in out
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "saddle_point_petsc_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "sp_oracle" not in txt and "libsp_oracle" not in txt, f
+
+
+# --------------------------------------------------------------------------- assembler
+@pytest.mark.parametrize("mx,my", [(4, 4), (9, 9), (32, 32), (7, 5), (3, 6)])
+def test_assembler_bitwise_equals_oracle(spk, oracle, mx, my):
+    A, f = spk.AssembleOperator_Laplace(mx, my, nthreads=3)
+    Ao, fo = oracle.assemble(mx, my)
+    assert np.array_equal(A.rowptr, Ao.rowptr) and np.array_equal(A.colidx, Ao.colidx)
+    assert np.array_equal(A.val, Ao.val) and np.array_equal(f, fo)
+    A2, f2 = spk.AssembleOperator_Laplace(mx, my, apply_bc=False, nthreads=1)
+    Ao2, fo2 = oracle.assemble(mx, my, bc=False)
+    assert np.array_equal(A2.val, Ao2.val) and np.array_equal(f2, fo2)
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    Bo, go = oracle.assemble_constraints(mx, my)
+    assert np.array_equal(B.rowptr, Bo.rowptr) and np.array_equal(B.colidx, Bo.colidx)
+    assert np.array_equal(B.val, Bo.val) and np.array_equal(g, go)
+
+
+def test_assembler_matches_m4_fixture(spk, golden_m4):
+    A, f = spk.AssembleOperator_Laplace(4)
+    assert np.array_equal(A.val, golden_m4["val"]) and np.array_equal(f, golden_m4["f"])
+
+
+def test_element_kernels_known_answer(spk, appendix_b):
+    Ke = spk.FormStressOperatorQ12D([0, 0, 0, 0.5, 0.5, 0.5, 0.5, 0])
+    assert np.abs(Ke - np.array(appendix_b["Ke"])).max() < appendix_b["Ke_tol"]
+    Fe = spk.FormLaplaceRHSQ12D([0, 0, 0, 0.5, 0.5, 0.5, 0.5, 0])
+    assert np.allclose(Fe, 0.25 / 4 * np.array(appendix_b["Fe_over_h2_quarter"]), rtol=1e-11)
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_slabs_concatenate_to_the_full_matrix(spk, P):
+    mx, my = 12, 19
+    A, f = spk.AssembleOperator_Laplace(mx, my)
+    B, _ = spk.AssembleOperator_Constraints(mx, my)
+    rp, ci, va, ff, nb = [0], [], [], [], 0
+    ends = []
+    for r in range(P):
+        b, e = spk.partition_slab(mx, my, r, P)
+        ends.append((b, e))
+        As, fs = spk.AssembleOperator_Laplace(mx, my, b, e)
+        assert As.row_begin == b and As.nrows == e - b
+        rp += list(As.rowptr[1:] + rp[-1]); ci += list(As.colidx); va += list(As.val); ff += list(fs)
+        Bs, _ = spk.AssembleOperator_Constraints(mx, my, b, e)
+        assert np.all((Bs.colidx >= b) & (Bs.colidx < e))
+        ref = B.col_slab(b, e)
+        assert np.array_equal(Bs.rowptr, ref.rowptr) and np.array_equal(Bs.colidx, ref.colidx) and np.array_equal(Bs.val, ref.val)
+        nb += Bs.nnz
+    assert ends[0][0] == 0 and ends[-1][1] == A.nrows and all(ends[i][1] == ends[i + 1][0] for i in range(P - 1))
+    lines = [(e - b) // (2 * mx) for b, e in ends]
+    assert max(lines) - min(lines) <= 1
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx) and np.array_equal(va, A.val) and np.array_equal(ff, f)
+    assert nb == B.nnz
+
+
+def test_assembler_rejects_bad_arguments(spk):
+    with pytest.raises(spk.SpkError):
+        spk.AssembleOperator_Laplace(8, 8, 3, 16)          # not whole node lines
+    with pytest.raises(spk.SpkError):
+        spk.grid_sizes(1, 5)
+    with pytest.raises(spk.SpkError):
+        spk.AssembleOperator_Constraints(2, 2)
+
+
+# --------------------------------------------------------------------------- partition
+def _split(spk, A):
+    i64, i32 = C.c_int64, C.c_int32
+    nd, no, ng = i64(), i64(), i32()
+    args = (A.row_begin, A.nrows, A.rowptr, A.colidx, A.val)
+    assert spk.lib.spk_partition_split(*args, *([None] * 7), C.byref(nd), C.byref(no), C.byref(ng)) == 0
+    drp, orp = np.zeros(A.nrows + 1, np.int32), np.zeros(A.nrows + 1, np.int32)
+    dci, oci = np.zeros(nd.value, np.int32), np.zeros(max(no.value, 1), np.int32)
+    dv, ov = np.zeros(nd.value), np.zeros(max(no.value, 1))
+    ga = np.zeros(max(ng.value, 1), np.int32)
+    p = lambda a: a.ctypes.data
+    assert spk.lib.spk_partition_split(*args, p(drp), p(dci), p(dv), p(orp), p(oci), p(ov), p(ga),
+                                       C.byref(nd), C.byref(no), C.byref(ng)) == 0
+    return drp, dci, dv, orp, oci[:no.value], ov[:no.value], ga[:ng.value]
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+def test_split_reproduces_the_slab_product(spk, oracle, P):
+    mx = my = 16
+    A, _ = spk.AssembleOperator_Laplace(mx, my)
+    x = np.random.default_rng(5).standard_normal(A.nrows)
+    y_ref = oracle.spmv(A, x)
+    y = np.zeros_like(x)
+    for r in range(P):
+        b, e = spk.partition_slab(mx, my, r, P)
+        As = A.slab(b, e)
+        drp, dci, dv, orp, oci, ov, ga = _split(spk, As)
+        assert np.all(np.diff(ga) > 0) and np.all((ga < b) | (ga >= e))       # sorted ghosts, all off-rank
+        assert dci.size == 0 or (dci.min() >= 0 and dci.max() < e - b)
+        if P == 1:
+            assert ga.size == 0
+        else:
+            # slab partition: ghosts are exactly the adjacent node lines
+            lo = np.arange(b - 2 * mx, b) if r > 0 else np.array([], int)
+            hi = np.arange(e, e + 2 * mx) if r < P - 1 else np.array([], int)
+            assert np.array_equal(ga, np.concatenate([lo, hi]))
+        xl, xg = x[b:e], x[ga]
+        for i in range(e - b):
+            y[b + i] = dv[drp[i]:drp[i + 1]] @ xl[dci[drp[i]:drp[i + 1]]] + ov[orp[i]:orp[i + 1]] @ xg[oci[orp[i]:orp[i + 1]]]
+    assert np.allclose(y, y_ref, rtol=1e-13, atol=1e-15)
+
+
+def test_partition_slab_matches_petsc_dmda_split(spk):
+    # 19 lines over 4 ranks: 5,5,5,4 (first nlines % nranks ranks get one more)
+    got = [spk.partition_slab(3, 19, r, 4) for r in range(4)]
+    assert [(e - b) // 6 for b, e in got] == [5, 5, 5, 4]
+    b, e = C.c_int64(), C.c_int64()
+    assert spk.lib.spk_partition_slab(10, 4, 5, 4, C.byref(b), C.byref(e)) != 0       # rank out of range
+
+
+# --------------------------------------------------------------------------- option parser
+def test_ksp_options_follow_the_petsc_names(spk):
+    k = spk.KSP()
+    k.setFromOptions("-ksp_type fgmres -ksp_rtol 1e-8 -ksp_atol 1e-30 -ksp_divtol 1e6 -ksp_max_it 250 "
+                     "-ksp_gmres_restart 20 -pc_type fieldsplit -pc_fieldsplit_type schur "
+                     "-pc_fieldsplit_schur_fact_type lower -pc_fieldsplit_schur_precondition selfp "
+                     "-fieldsplit_0_ksp_type preonly -fieldsplit_0_pc_type jacobi -fieldsplit_1_pc_type jacobi "
+                     "-ksp_initial_guess_nonzero -da_grid_x 32 -log_view")
+    o, pc, sf = k.getOptions()
+    assert (o.rtol, o.abstol, o.dtol, o.max_it, o.restart, o.guess_nonzero) == (1e-8, 1e-30, 1e6, 250, 20, 1)
+    assert pc == spk.PC_SCHUR and sf == spk.SCHUR_LOWER
+    for bad in ("-ksp_type cg", "-pc_type ilu", "-ksp_rtol", "-ksp_rtol abc", "-ksp_gmres_modifiedgramschmidt",
+                "-ksp_bogus 3", "-pc_fieldsplit_schur_fact_type half", "-fieldsplit_0_pc_type lu"):
+        with pytest.raises(spk.SpkError):
+            k.setFromOptions(bad)
+    # negative numbers are values, not option names
+    k.setFromOptions("-ksp_max_it 7 -ksp_rtol 1e-3")
+    assert k.getOptions()[0].max_it == 7
+    # call order errors, as PETSc raises them
+    with pytest.raises(spk.SpkError):
+        k.setUp()                                   # no operators yet
+    k.destroy()
+    assert spk.lib.SpkKSPConvergedReasonName(2) == b"CONVERGED_RTOL"
+    assert spk.lib.SpkKSPConvergedReasonName(-3) == b"DIVERGED_ITS"
