@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- FGMRES iterations/s on the saddle-point system + achieved HBM
+GB/s of the A-block SpMV (BASELINE.json's metric), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 300 --warmup 30
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): the 1024 x 1024 DMDA node grid of BASELINE.json's
+configs (2 097 152 rows, 37 699 600 stored non-zeros in A, 4 constraint rows),
+K = [A B^T; B 0], FGMRES(30) with classical Gram-Schmidt and the full Schur
+fieldsplit preconditioner S^ = diag(B diag(A)^-1 B^T): the call the reference
+makes at /root/reference/src/SaddlePointProblem.c:70 with the finished nest.
+The whole system fits one MI355X; N > 1 row-partitions the SAME system (strong
+scaling) with RCCL all-reduces and halo send/recv on the solver's stream.
+
+A "step" is one FGMRES iteration.  Exactly K iterations are timed: rtol = atol
+= 0 so the solve cannot stop early, and spk_fgmres stops at max_it = K.  b and x
+live in device memory before the clock starts.  The timed region contains the
+whole KSPSolve for those K iterations (||b||, the restarts' true residuals, the
+solution update).
+
+Only the cpu_baseline leg touches oracle/ (the CPU restatement), as a reported
+baseline on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured float4 copy ceiling, same guide
+METRIC = "FGMRES iterations/sec + achieved HBM GB/s on A-block SpMV, 1/2/4/8 MI355X"
+
+
+def spmv_bytes(nrows, nnz):
+    """Algorithmic bytes of one CSR SpMV:
+    12 B per stored non-zero + 4 B row pointer + x once + y once per row."""
+    return 12 * nnz + 4 * (nrows + 1) + 16 * nrows
+
+
+def iteration_bytes(n, nnz, nnzB, restart):
+    """Algorithmic bytes of ONE average FGMRES(restart) iteration of this
+    implementation on the saddle system with the full Schur PC:
+    SpMV on A (+ B^T fused) + B products + Gram-Schmidt + PC streams."""
+    j_avg = (restart - 1) / 2.0
+    spmv = spmv_bytes(n, nnz) + 12 * nnzB + 4 * n            # A stream + B^T rows fused in
+    bdots = 2 * (12 * nnzB + 8 * n) + 8 * n                   # B z0 and B (D x0) (+ dinv)
+    gs = ((j_avg + 2) + (j_avg + 3)) * 8 * n + 2 * 8 * n      # mdot, maxpy(+norm), scale
+    pc = (12 * nnzB + 4 * n) + 3 * 8 * n                      # bt_update: B^T rows, dinv, x0, z0
+    upd = (restart + 2 + 4) * 8 * n / restart + spmv / restart  # x += Z y, true residual, per cycle
+    return spmv + bdots + gs + pc + upd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--grid", type=int, default=1024, help="DMDA nodes per side")
+    ap.add_argument("--pc", default="schur-full", choices=["schur-full", "schur-lower", "schur-upper", "schur-diag", "jacobi"])
+    ap.add_argument("--restart", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-its", type=int, default=30)
+    ap.add_argument("--spmv-reps", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import saddle_point_petsc_amd as S   # fails loudly if libspk.so is not built
+
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    M = args.grid
+    n, nnz_global = S.grid_sizes(M)
+    t_setup = time.time()
+    rb, re_ = S.partition_slab(M, M, rank, world)
+    A, f = S.AssembleOperator_Laplace(M, M, rb, re_)
+    saddle = args.pc != "jacobi"
+    B = g = None
+    if saddle:
+        B, g = S.AssembleOperator_Constraints(M, M, rb, re_)
+    ctx = S.Context(local_rank)
+    if world > 1:
+        ids = [S.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init_rccl(rank, world, ids[0])
+    ctx.set_block(S.BLOCK_A00, A)
+    if saddle:
+        ctx.set_block(S.BLOCK_A10, B)
+    pc = S.PC_JACOBI if not saddle else S.PC_SCHUR
+    fact = {"schur-full": S.SCHUR_FULL, "schur-lower": S.SCHUR_LOWER, "schur-upper": S.SCHUR_UPPER,
+            "schur-diag": S.SCHUR_DIAG, "jacobi": S.SCHUR_FULL}[args.pc]
+    ctx.pc_setup(pc, fact)
+    rhs = np.concatenate([f, g]) if saddle else f
+    b_dev = ctx.vec_create(rhs)
+    x_dev = ctx.vec_create(n=len(rhs))
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300)
+    # ---- warm-up: W untimed iterations
+    if args.warmup > 0:
+        ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
+    # ---- timed: exactly K iterations
+    barrier()
+    t0 = time.perf_counter()
+    info = ctx.fgmres_device(b_dev, x_dev, max_it=args.steps, **kw)   # synchronous at return
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert info["its"] == args.steps, info
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel named by the metric: A-block SpMV, HIP events on the solver's stream
+    spmv_ms = ctx.time_spmv(warmup=20, reps=args.spmv_reps)
+    sz = ctx.sizes()
+    alg_bytes = spmv_bytes(sz["n_local"], sz["nnz_local"])
+    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tpath) and world == 1 and M == 1024:
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    its_per_s = args.steps / elapsed
+    nnzB_local = B.nnz if saddle else 0
+    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart) if saddle else None
+    out = {
+        "metric": METRIC,
+        "value": its_per_s,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{M}x{M} DMDA node grid, dof 2 (n={n}, nnz(A)={nnz_global}), "
+                               + ("saddle K=[A B^T;B 0] with 4 constraint rows, " if saddle else "K=A, ")
+                               + f"FGMRES({args.restart}) CGS, pc={args.pc}",
+                   "grid": M, "rows": n + (4 if saddle else 0), "pc": args.pc, "restart": args.restart,
+                   "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},
+        "spmv_gbps": achieved,
+        "spmv_ms": spmv_ms,
+        "residual_after_steps": info["rnorm"] / info["rnorm0"] if info["rnorm0"] else None,
+        "setup_seconds": t_setup,
+        "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel (A-block CSR SpMV)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                     "bytes_per_launch": alg_bytes, "traffic": traffic},
+    }
+    if it_bytes:
+        out["iteration_model"] = {"bytes_per_iteration": it_bytes,
+                                  "achieved_gbps": it_bytes * its_per_s / 1e9,
+                                  "frac_of_peak": it_bytes * its_per_s / 1e9 / HBM_PEAK_GBS}
+
+    # ---- CPU baseline: the oracle (a port of PETSc's algorithm; PETSc itself is not
+    # installable here) on a bounded sample of the SAME workload, all host cores.
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle as O
+        cores = os.cpu_count() or 1
+        Ao = O.CSR(A.rowptr, A.colidx, A.val, A.ncols)
+        Bo = O.CSR(B.rowptr, B.colidx, B.val, B.ncols) if saddle else None
+        k = max(1, args.cpu_its)
+        t0 = time.perf_counter()
+        _, io = O.fgmres(Ao, rhs, B=Bo, pc_type=O.PC_SCHUR if saddle else O.PC_JACOBI, schur_fact=fact,
+                         restart=args.restart, max_it=k, rtol=0.0, abstol=0.0, dtol=1e300, threads=cores)
+        tc = time.perf_counter() - t0
+        t_spmv = O.time_spmv(Ao, 5, cores) / 5
+        out["cpu_baseline"] = {"value": io["its"] / tc, "unit": "iterations/s", "cores": cores, "kind": "port",
+                               "sample": f"{io['its']} FGMRES iterations (one restart cycle) of the same {M}x{M} "
+                                         f"system with the oracle, OpenMP over {cores} threads",
+                               "spmv_gbps": spmv_bytes(A.nrows, A.nnz) / t_spmv / 1e9,
+                               "label": "PETSc-equivalent CPU restatement (PETSc not installable offline)"}
+        out["speedup_vs_cpu"] = its_per_s / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

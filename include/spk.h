@@ -148,6 +148,14 @@ int spk_pc_apply(spk_ctx *ctx, const double *x, double *y, int mem);
 int spk_fgmres(spk_ctx *ctx, const double *b, double *x, int mem, const spk_opts *opts,
                spk_result *result, double *history, int32_t history_cap);
 
+/* ---- device vectors for callers that keep b/x resident in HBM --------------- */
+/* (a PCSHELL/MATSHELL glue over device Vecs, bench.py).  Zero-filled, length
+ * rounded up so that every kernel may read whole 16-byte pairs. */
+int spk_vec_create(spk_ctx *ctx, int64_t n, double **dev);
+int spk_vec_destroy(spk_ctx *ctx, double *dev);
+int spk_vec_set(spk_ctx *ctx, double *dev, const double *host, int64_t n);
+int spk_vec_get(spk_ctx *ctx, const double *dev, double *host, int64_t n);
+
 /* ---- sizes ---------------------------------------------------------------- */
 int spk_get_sizes(const spk_ctx *ctx, int64_t *n_global, int32_t *n_local, int32_t *m,
                   int64_t *nnz_local, int32_t *n_ghost);

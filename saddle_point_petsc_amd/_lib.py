@@ -74,6 +74,10 @@ def _load():
     L.spk_mult.argtypes = [vp, f64p, f64p, C.c_int]
     L.spk_pc_apply.argtypes = [vp, f64p, f64p, C.c_int]
     L.spk_fgmres.argtypes = [vp, f64p, f64p, C.c_int, C.POINTER(Opts), C.POINTER(Result), vp, i32]
+    L.spk_vec_create.argtypes = [vp, i64, C.POINTER(vp)]
+    L.spk_vec_destroy.argtypes = [vp, vp]
+    L.spk_vec_set.argtypes = [vp, vp, f64p, i64]
+    L.spk_vec_get.argtypes = [vp, vp, f64p, i64]
     L.spk_get_sizes.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
     L.spk_kernel_mdot.argtypes = [vp, i64, i32, f64p, i64, f64p, f64p]
     L.spk_kernel_maxpy.argtypes = [vp, i64, i32, f64p, f64p, i64, f64p, C.POINTER(dbl)]

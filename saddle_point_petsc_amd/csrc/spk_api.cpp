@@ -239,6 +239,40 @@ int spk_fgmres(spk_ctx *c, const double *b, double *x, int mem, const spk_opts *
     SPK_CATCH(c)
 }
 
+int spk_vec_create(spk_ctx *c, int64_t n, double **dev)
+{
+    SPK_TRY(c)
+    if (!dev || n < 0) spk::fail(SPK_ERR_ARG, "spk_vec_create: bad arguments");
+    const size_t len = (size_t)((n + 255) / 256 * 256 + 256);
+    SPK_HIP(hipMalloc((void **)dev, len * sizeof(double)));
+    SPK_HIP(hipMemset(*dev, 0, len * sizeof(double)));
+    SPK_CATCH(c)
+}
+
+int spk_vec_destroy(spk_ctx *c, double *dev)
+{
+    SPK_TRY(c)
+    if (dev) SPK_HIP(hipFree(dev));
+    SPK_CATCH(c)
+}
+
+int spk_vec_set(spk_ctx *c, double *dev, const double *host, int64_t n)
+{
+    SPK_TRY(c)
+    if (!dev || !host || n < 0) spk::fail(SPK_ERR_ARG, "spk_vec_set: bad arguments");
+    SPK_HIP(hipMemcpy(dev, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    SPK_CATCH(c)
+}
+
+int spk_vec_get(spk_ctx *c, const double *dev, double *host, int64_t n)
+{
+    SPK_TRY(c)
+    if (!dev || !host || n < 0) spk::fail(SPK_ERR_ARG, "spk_vec_get: bad arguments");
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    SPK_HIP(hipMemcpy(host, dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    SPK_CATCH(c)
+}
+
 // ---- single kernels through the ABI -----------------------------------------
 int spk_kernel_mdot(spk_ctx *c, int64_t n, int32_t nv, const double *V, int64_t ldv, const double *w, double *h)
 {

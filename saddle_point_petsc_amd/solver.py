@@ -134,6 +134,41 @@ class Context:
                        cycles=res.cycles, solve_seconds=res.solve_seconds,
                        history=hist[:res.hist_len].copy())
 
+    # ---- device-resident vectors (inputs already in HBM when a solve starts)
+    def vec_create(self, host=None, n=None):
+        n = len(host) if host is not None else n
+        p = C.c_void_p()
+        self._chk(lib.spk_vec_create(self.h, n, C.byref(p)))
+        if host is not None:
+            self._chk(lib.spk_vec_set(self.h, p, np.ascontiguousarray(host, np.float64), n))
+        return p
+
+    def vec_get(self, p, n):
+        out = np.zeros(n)
+        self._chk(lib.spk_vec_get(self.h, p, out, n))
+        return out
+
+    def vec_destroy(self, p):
+        self._chk(lib.spk_vec_destroy(self.h, p))
+
+    def fgmres_device(self, b_dev, x_dev, **kw):
+        """KSPSolve on vectors that already live in device memory."""
+        o = default_opts(**kw)
+        res = Result()
+        cap = int(min(o.max_it + 2, 1 << 22))
+        hist = np.zeros(cap)
+        f = lib.spk_fgmres
+        old = f.argtypes
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Opts), C.POINTER(Result), C.c_void_p, C.c_int32]
+        try:
+            rc = f(self.h, b_dev, x_dev, MEM_DEVICE, C.byref(o), C.byref(res), hist.ctypes.data, cap)
+        finally:
+            f.argtypes = old
+        self._chk(rc)
+        return dict(its=res.its, reason=res.reason, rnorm=res.rnorm, rnorm0=res.rnorm0,
+                    cycles=res.cycles, solve_seconds=res.solve_seconds,
+                    history=hist[:res.hist_len].copy())
+
     def mdot(self, V, w):
         V = np.ascontiguousarray(V, np.float64)
         w = np.ascontiguousarray(w, np.float64)
