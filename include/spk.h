@@ -172,8 +172,12 @@ int spk_kernel_maxpy(spk_ctx *ctx, int64_t n, int32_t nv, const double *a, const
  * context's stream after `warmup` untimed launches; *ms_per_launch = average.
  * x is a deterministic fill sin(0.37 i). */
 int spk_time_spmv(spk_ctx *ctx, int warmup, int reps, double *ms_per_launch);
-/* Same for one full FGMRES-cycle kernel sequence is done by spk_fgmres itself
- * (spk_result.solve_seconds). */
+/* Generic form for the other kernels of an iteration (tuning / profiles):
+ * which = "spmv" | "mult" | "pc" | "mdot" | "maxpy" | "scale" | "wide_dot" |
+ * "bt_update"; nv = vectors for mdot/maxpy.  Needs operators (and pc_setup for
+ * "pc"); allocates its own scratch vectors. */
+int spk_time_kernel(spk_ctx *ctx, const char *which, int nv, int warmup, int reps,
+                    double *ms_per_launch);
 
 /* ---- host-only helpers: row-slab partition and halo plan ------------------ */
 /* (callable without a GPU; used by the multi-rank CPU tests) */

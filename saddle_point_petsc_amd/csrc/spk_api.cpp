@@ -3,6 +3,7 @@
 // host vectors.  The work is in spk_solver.cpp / spk_kernels.hip.
 #include <cmath>
 #include <cstring>
+#include <string>
 
 #include "spk_internal.hpp"
 
@@ -287,9 +288,7 @@ int spk_kernel_mdot(spk_ctx *c, int64_t n, int32_t nv, const double *V, int64_t 
     for (int i = 0; i < nv; ++i)
         SPK_HIP(hipMemcpy(dV.p + (size_t)ld * i, V + (size_t)ldv * i, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
     SPK_HIP(hipMemcpy(dw.p, w, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    int nb = 0;
-    spk::k::mdot(dV.p, ld, nv, dw.p, n, n, c->partials.p, &nb, nullptr, c->stream);
-    spk::k::reduce_partials(c->partials.p, nb, spk::k::kPartialLd, nv + 1, c->small.p, nullptr, c->stream);
+    spk::k::mdot(dV.p, ld, nv, dw.p, n, n, c->fin(c->small.p), nullptr, c->stream);
     SPK_HIP(hipStreamSynchronize(c->stream));
     SPK_HIP(hipMemcpy(h, c->small.p, sizeof(double) * (size_t)(nv + 1), hipMemcpyDeviceToHost));
     SPK_CATCH(c)
@@ -310,9 +309,7 @@ int spk_kernel_maxpy(spk_ctx *c, int64_t n, int32_t nv, const double *a, const d
     for (int i = 0; i < nv; ++i)
         SPK_HIP(hipMemcpy(dV.p + (size_t)ld * i, V + (size_t)ldv * i, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
     SPK_HIP(hipMemcpy(dw.p, w, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    int nb = 0;
-    spk::k::maxpy(dV.p, ld, nv, nullptr, da.p, 1.0, dw.p, n, n, c->partials.p, &nb, nullptr, c->stream);
-    spk::k::reduce_partials(c->partials.p, nb, spk::k::kPartialLd, 1, c->small.p, nullptr, c->stream);
+    spk::k::maxpy(dV.p, ld, nv, nullptr, da.p, 1.0, dw.p, n, n, c->fin(c->small.p), nullptr, c->stream);
     SPK_HIP(hipStreamSynchronize(c->stream));
     SPK_HIP(hipMemcpy(w, dw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
     if (nrm2) SPK_HIP(hipMemcpy(nrm2, c->small.p, sizeof(double), hipMemcpyDeviceToHost));
@@ -336,6 +333,56 @@ int spk_time_spmv(spk_ctx *c, int warmup, int reps, double *ms_per_launch)
     SPK_HIP(hipEventRecord(e0, c->stream));
     for (int i = 0; i < reps; ++i) spk::k::spmv(c->Ad, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
     SPK_HIP(hipEventRecord(e1, c->stream));
+    SPK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SPK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / reps;
+    SPK_CATCH(c)
+}
+
+int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps, double *ms_per_launch)
+{
+    SPK_TRY(c)
+    if (!which || !ms_per_launch || reps < 1 || warmup < 0) spk::fail(SPK_ERR_ARG, "spk_time_kernel: bad arguments");
+    if (!c->have_A) spk::fail(SPK_ERR_STATE, "spk_time_kernel: no operator");
+    if (nv < 0 || nv > spk::k::kMaxNv - 2) spk::fail(SPK_ERR_ARG, "spk_time_kernel: nv out of range");
+    c->ensure_scratch();
+    c->ensure_vectors();
+    const std::string w(which);
+    const int64_t N = (int64_t)c->n_local + c->m, ld = c->ld;
+    spk::DevBuf<double> V, coef;
+    V.alloc((size_t)ld * (size_t)(nv + 2));
+    {
+        std::vector<double> h((size_t)ld, 0.0);
+        for (int j = 0; j < nv + 2; ++j) {
+            for (int64_t i = 0; i < N; ++i) h[(size_t)i] = std::sin(0.37 * (double)i + (double)j) * 1e-3;
+            SPK_HIP(hipMemcpy(V.p + (size_t)ld * j, h.data(), sizeof(double) * (size_t)ld, hipMemcpyHostToDevice));
+        }
+        std::vector<double> a((size_t)nv + 8, 1e-6);
+        coef.upload(a.data(), a.size(), 8);
+    }
+    double *x = V.p + (size_t)ld * nv, *y = V.p + (size_t)ld * (nv + 1);
+    hipStream_t s = c->stream;
+    auto run = [&]() {
+        if (w == "spmv") spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s);
+        else if (w == "mult") spk::op_mult(c, x, y, nullptr);
+        else if (w == "pc") { if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "pc not set up"); spk::op_pc_apply(c, x, y, nullptr); }
+        else if (w == "mdot") spk::k::mdot(V.p, ld, nv, x, N, N, c->fin(c->small.p), nullptr, s);
+        else if (w == "maxpy") spk::k::maxpy(V.p, ld, nv, nullptr, coef.p, -1.0, x, N, N, c->fin(c->small.p + 64), nullptr, s);
+        else if (w == "scale") spk::k::scale_dev(x, N, coef.p, nullptr, s);
+        else if (w == "wide_dot") { if (!c->have_B) spk::fail(SPK_ERR_STATE, "no B"); spk::k::wide_dot(c->B, x, c->fin(c->small.p), nullptr, s); }
+        else if (w == "bt_update") { if (!c->have_B || !c->pc_ready) spk::fail(SPK_ERR_STATE, "no B / pc"); spk::k::bt_update(1, c->Bt, c->dinv.p, x, c->small.p + 200, y, nullptr, s); }
+        else spk::fail(SPK_ERR_ARG, "spk_time_kernel: unknown kernel '%s'", which);
+    };
+    hipEvent_t e0, e1;
+    SPK_HIP(hipEventCreate(&e0));
+    SPK_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) run();
+    SPK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) run();
+    SPK_HIP(hipEventRecord(e1, s));
     SPK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     SPK_HIP(hipEventElapsedTime(&ms, e0, e1));

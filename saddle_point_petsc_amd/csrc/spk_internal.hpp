@@ -151,39 +151,44 @@ constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
 
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row);
 
+// where a reducing kernel leaves its result: block partials, the arrival
+// counter of the "last workgroup finishes" protocol, and the output slot
+struct Finish {
+    double *partials;
+    unsigned *counter;
+    double *out;
+};
+
 // y = A x  (+ Bt-rows * lam when bt != nullptr); CSR stream kernel
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
           const int32_t *done, hipStream_t s);
 // y[rows[i]] += Ao_row_i . xg   (compressed off-rank block)
 void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
                   const int32_t *done, hipStream_t s);
-// partial[w*m + r] = sum over window w of B_r . x ; then reduce_partials
-void wide_dot(const WideDev &B, const double *x, double *partials, const int32_t *done, hipStream_t s);
+// f.out[r] = B_r . x, r < m
+void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s);
 // same with x replaced by x .* dinv (the B D x0 step of the Schur PC, no stored D x0)
-void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, double *partials,
+void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, const Finish &f,
                      const int32_t *done, hipStream_t s);
 // dense[col] = val*dinv[col] over entries [k0,k1) of B (dinv == nullptr: dense[col] = 0)
 void scatter_row(const int32_t *colidx, const double *val, int k0, int k1, const double *dinv,
                  double *dense, hipStream_t s);
 // out[i] = sum_r slots[r*ld + i] in rank order (local-group all-reduce)
 void sum_slots(const double *slots, int nslots, int ld, int count, double *out, hipStream_t s);
-// out[i] = sum_b partials[b*ld + i], fixed order
-void reduce_partials(const double *partials, int nb, int ld, int k, double *out,
-                     const int32_t *done, hipStream_t s);
-// h partials for i < nv:  V_i . w ; plus w.w at slot nv
+// f.out[i] = V_i . w for i < nv, f.out[nv] = w.w
 void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
-          double *partials, int *nblocks, const int32_t *done, hipStream_t s);
-// w += sum_i coef_sign * a[i] * V_i ; partials of ||w_new||^2 (first n_dot entries)
+          const Finish &f, const int32_t *done, hipStream_t s);
+// w += sign * sum_i a[i] * V_i ; f.out[0] = ||w_new||^2 over the first n_dot entries
+// (f.out == nullptr: no norm)
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
-           double coef_sign, double *w, int64_t n, int64_t n_dot, double *partials, int *nblocks,
+           double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
            const int32_t *done, hipStream_t s);
 // x *= *alpha_dev
 void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s);
 // y = a*x + b*y with host scalars (b = 0: y = a*x without reading y)
 void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s);
-// partials of x.x over the first n_dot entries
-void sqnorm(const double *x, int64_t n_dot, double *partials, int *nblocks, const int32_t *done,
-            hipStream_t s);
+// f.out[0] = x.x over the first n_dot entries
+void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s);
 // gather x[idx[i]] -> out[i]
 void gather(const double *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s);
 // Jacobi / Schur pieces
@@ -249,6 +254,8 @@ struct spk_ctx {
     // scratch
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd
     spk::DevBuf<double> small;     // reduced scalars (256 doubles)
+    spk::DevBuf<unsigned> counters; // arrival counters of the last-workgroup finish
+    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, counters.p, out}; }
     spk::DevBuf<double> y1tmp, ttmp;
 
     // Krylov workspace (sized by restart)

@@ -18,6 +18,7 @@
 #include "spk_internal.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace spk {
 namespace k {
@@ -26,8 +27,13 @@ constexpr int kThreads = 256;
 constexpr int kWave = 64;
 constexpr int kTileNnz = 4096;   // products staged in LDS per workgroup: 32 KiB
 constexpr int kTileRows = 256;   // rows per tile <= threads
+// Reducing vector kernels run 1024-thread workgroups on a grid of <= 256 (one per
+// CU): the "last workgroup finishes" protocol costs one same-address atomic per
+// workgroup (~12 ns each, serialised), so few fat workgroups beat many thin ones.
+constexpr int kVT = 1024;
+constexpr int kVWaves = kVT / kWave;
 constexpr int kVecUnroll = 4;    // double2 per thread per vector tile
-constexpr int kVecTile2 = kThreads * kVecUnroll;  // double2 per tile (2048 doubles)
+constexpr int kVecMaxBlocks = 256;
 
 // ---------------------------------------------------------------------------
 // reductions inside a workgroup
@@ -37,6 +43,73 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// Cross-workgroup finish without a second launch and without fences
+// (cdna_hip_programming.md Guideline 16, form R1 + "the workgroup whose add came
+// last"): every workgroup PUBLISHES its k partial sums with sc1 (write-through)
+// stores, drains them (s_waitcnt vmcnt(0)) and makes ONE agent-scope atomic add;
+// the workgroup whose add returns gridDim-1 re-reads all partials with sc1
+// loads and sums them in a FIXED order (bitwise reproducible, no float atomics).
+// The counter is reset by that workgroup, so the next launch on the stream
+// finds it at zero.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void publish(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double peek(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true in every thread of the workgroup that arrived last (nblocks arrivals expected)
+__device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned nblocks, int *flag_lds)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag_lds = (old == nblocks - 1);
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
+
+// last workgroup (blockDim.x = T threads, power of two): scratch[i] = sum_b partials[b*ld + i],
+// i < k <= 64.  Strided slices (loads issued in batches of 8 before the adds), then a fixed
+// binary tree; the result is valid in LDS scratch[0..k) after return.  scratch: T doubles.
+__device__ __forceinline__ void final_reduce(const double *partials, int nb, int ld, int k, double *scratch)
+{
+    const int T = blockDim.x;
+    int kk = 1;
+    while (kk < k) kk <<= 1;
+    const int i = threadIdx.x & (kk - 1), sl = threadIdx.x / kk, nsl = T / kk;
+    double acc = 0.0;
+    if (i < k) {
+        for (int b0 = sl; b0 < nb; b0 += nsl * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * nsl;
+                v[u] = b < nb ? peek(partials + (size_t)b * ld + i) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+    }
+    scratch[sl * kk + i] = acc;
+    __syncthreads();
+    for (int st = nsl >> 1; st > 0; st >>= 1) {
+        if (sl < st) scratch[sl * kk + i] += scratch[(sl + st) * kk + i];
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void reset_counter(unsigned *counter)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------
@@ -172,80 +245,70 @@ void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, doubl
 }
 
 // ---------------------------------------------------------------------------
-// B x for the short-and-wide constraint block: one workgroup per column window,
-// all m rows, so x (optionally x .* scale) is streamed once.
+// B x for the short-and-wide constraint block (4 rows of ~n/2 entries): one
+// workgroup per (column window, row), 16-byte loads of the row's entries in the
+// window, x (optionally x .* scale) gathered; the last workgroup sums the
+// window partials of each row in window order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void wide_dot_kernel(
+__global__ __launch_bounds__(kVT) void wide_dot_kernel(
     const int32_t *__restrict__ colidx, const double *__restrict__ val,
-    const int32_t *__restrict__ winptr, int m, const double *__restrict__ x,
-    const double *__restrict__ scale, double *__restrict__ partials, const int32_t *__restrict__ done)
+    const int32_t *__restrict__ winptr, int m, int nwin, const double *__restrict__ x,
+    const double *__restrict__ scale, double *__restrict__ partials, unsigned *__restrict__ counter,
+    double *__restrict__ out, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
-    __shared__ double red[4];
+    __shared__ double scratch[kVT];
+    __shared__ int last;
     const int w = blockIdx.x;
     for (int r = 0; r < m; ++r) {
         const int k0 = winptr[w * m + r], k1 = winptr[(w + 1) * m + r];
+        const int a0 = k0 & ~3;
         double acc = 0.0;
-        if (scale) {
-            for (int k = k0 + threadIdx.x; k < k1; k += kThreads) {
-                const int c = colidx[k];
-                acc += val[k] * (x[c] * scale[c]);
+        for (int q = a0 + (int)threadIdx.x * 4; q < k1; q += kVT * 4) {
+            const int4 c = *reinterpret_cast<const int4 *>(colidx + q);
+            const double2 v0 = *reinterpret_cast<const double2 *>(val + q);
+            const double2 v1 = *reinterpret_cast<const double2 *>(val + q + 2);
+            double x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
+            if (scale) {
+                x0 *= scale[c.x]; x1 *= scale[c.y]; x2 *= scale[c.z]; x3 *= scale[c.w];
             }
-        } else {
-            for (int k = k0 + threadIdx.x; k < k1; k += kThreads) acc += val[k] * x[colidx[k]];
+            if (q >= k0 && q < k1) acc += v0.x * x0;
+            if (q + 1 >= k0 && q + 1 < k1) acc += v0.y * x1;
+            if (q + 2 >= k0 && q + 2 < k1) acc += v1.x * x2;
+            if (q + 3 >= k0 && q + 3 < k1) acc += v1.y * x3;
         }
-        const double s = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        const double sw = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = sw;
         __syncthreads();
-        if (threadIdx.x == 0) partials[(size_t)w * kPartialLd + r] = ((red[0] + red[1]) + red[2]) + red[3];
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < kVWaves; ++j) t += scratch[j];
+            publish(partials + (size_t)w * kPartialLd + r, t);
+        }
         __syncthreads();
     }
+    if (!arrive_last(counter, gridDim.x, &last)) return;
+    final_reduce(partials, nwin, kPartialLd, m, scratch);
+    if ((int)threadIdx.x < m) out[threadIdx.x] = scratch[threadIdx.x];
+    reset_counter(counter);
 }
 
-static void wide_dot_scaled(const WideDev &B, const double *x, const double *scale, double *partials,
+static void wide_dot_scaled(const WideDev &B, const double *x, const double *scale, const Finish &f,
                             const int32_t *done, hipStream_t s)
 {
     if (B.nwin == 0) return;
-    hipLaunchKernelGGL(wide_dot_kernel, dim3(B.nwin), dim3(kThreads), 0, s, B.colidx.p, B.val.p,
-                       B.winptr.p, B.m, x, scale, partials, done);
+    hipLaunchKernelGGL(wide_dot_kernel, dim3(B.nwin), dim3(kVT), 0, s, B.colidx.p, B.val.p,
+                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.counter, f.out, done);
 }
-void wide_dot(const WideDev &B, const double *x, double *partials, const int32_t *done, hipStream_t s)
+void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s)
 {
-    wide_dot_scaled(B, x, nullptr, partials, done, s);
+    wide_dot_scaled(B, x, nullptr, f, done, s);
 }
-void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, double *partials,
+void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, const Finish &f,
                      const int32_t *done, hipStream_t s)
 {
-    wide_dot_scaled(B, x, dinv, partials, done, s);
-}
-
-// out[i] = sum_b partials[b*ld + i], i < k <= 64: 16 strided slices, then a
-// fixed-order finish -> bitwise reproducible.
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double *__restrict__ partials,
-                                                               int nb, int ld, int k,
-                                                               double *__restrict__ out,
-                                                               const int32_t *__restrict__ done)
-{
-    if (done && *done) return;
-    __shared__ double sl[16][64];
-    const int i = threadIdx.x & 63, sidx = threadIdx.x >> 6;
-    double acc = 0.0;
-    if (i < k)
-        for (int b = sidx; b < nb; b += 16) acc += partials[(size_t)b * ld + i];
-    sl[sidx][i] = acc;
-    __syncthreads();
-    if ((int)threadIdx.x < k) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s += sl[j][threadIdx.x];
-        out[threadIdx.x] = s;
-    }
-}
-
-void reduce_partials(const double *partials, int nb, int ld, int k, double *out, const int32_t *done,
-                     hipStream_t s)
-{
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partials, nb, ld, k, out, done);
+    wide_dot_scaled(B, x, dinv, f, done, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -256,26 +319,46 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t i2)
 {
     return reinterpret_cast<const double2 *>(p)[i2];
 }
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+// streamed-once operand: non-temporal 16-byte load (global_load_dwordx4 ... nt)
+template <bool NT>
+__device__ __forceinline__ double2 ld2s(const double *p, int64_t i2)
+{
+    if (NT) {
+        const dbl2v v = __builtin_nontemporal_load(reinterpret_cast<const dbl2v *>(p) + i2);
+        double2 r;
+        r.x = v.x;
+        r.y = v.y;
+        return r;
+    }
+    return reinterpret_cast<const double2 *>(p)[i2];
+}
 
-template <int NG>
-__global__ __launch_bounds__(kThreads) void mdot_kernel(const double *__restrict__ V, int64_t ldv,
-                                                        int nv, const double *__restrict__ w,
-                                                        int64_t n2, int64_t n_dot,
-                                                        double *__restrict__ partials, int with_ww,
-                                                        const int32_t *__restrict__ done)
+// T threads per workgroup, G vectors loaded together (their 4*G 16-byte loads per
+// thread are all issued before the first FMA: the bytes in flight, not the
+// arithmetic, set the rate of this kernel).
+template <int NG, int T, int G, bool NT>
+__global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, int64_t ldv, int nv,
+                                                 const double *__restrict__ w, int64_t n2,
+                                                 int64_t n_dot, double *__restrict__ partials,
+                                                 int with_ww, unsigned *__restrict__ counter,
+                                                 double *__restrict__ out,
+                                                 const int32_t *__restrict__ done)
 {
     if (done && *done) return;
-    __shared__ double lds[4 * (NG * 8 + 1)];
-    double acc[NG * 8 + 1];
+    constexpr int NA = NG * 8 + 1, W = T / kWave, TILE2 = T * kVecUnroll;
+    __shared__ double lds[(W * NA > T) ? W * NA : T];
+    __shared__ int last;
+    double acc[NA];
 #pragma unroll
-    for (int i = 0; i < NG * 8 + 1; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NA; ++i) acc[i] = 0.0;
 
-    for (int64_t tile = blockIdx.x; tile * kVecTile2 < n2; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile * TILE2 < n2; tile += gridDim.x) {
         double2 wv[kVecUnroll];
         int64_t idx[kVecUnroll];
 #pragma unroll
         for (int u = 0; u < kVecUnroll; ++u) {
-            idx[u] = tile * kVecTile2 + u * kThreads + threadIdx.x;
+            idx[u] = tile * TILE2 + u * T + threadIdx.x;
             if (idx[u] < n2) {
                 wv[u] = ld2(w, idx[u]);
                 if (2 * idx[u] >= n_dot) wv[u].x = 0.0;
@@ -286,21 +369,25 @@ __global__ __launch_bounds__(kThreads) void mdot_kernel(const double *__restrict
             }
         }
 #pragma unroll
-        for (int u = 0; u < kVecUnroll; ++u) acc[NG * 8] += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
+        for (int u = 0; u < kVecUnroll; ++u) acc[NA - 1] += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g * 8 < nv) {
+        for (int g0 = 0; g0 < NG * 8; g0 += G) {
+            if (g0 < nv) {  // wave-uniform
+                double2 a[G][kVecUnroll];
 #pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    const int i = g * 8 + v;
-                    if (i < nv) {
-                        const double *Vi = V + (size_t)i * ldv;
-                        double2 a[kVecUnroll];
+                for (int v = 0; v < G; ++v) {
+                    const int ic = (g0 + v < nv) ? g0 + v : nv - 1;  // clamp: re-reads a cached vector
+                    const double *Vi = V + (size_t)ic * ldv;
 #pragma unroll
-                        for (int u = 0; u < kVecUnroll; ++u) a[u] = ld2(Vi, idx[u]);
+                    for (int u = 0; u < kVecUnroll; ++u) a[v][u] = ld2s<NT>(Vi, idx[u]);
+                }
 #pragma unroll
-                        for (int u = 0; u < kVecUnroll; ++u) acc[i] += a[u].x * wv[u].x + a[u].y * wv[u].y;
-                    }
+                for (int v = 0; v < G; ++v) {
+                    const double mk = (g0 + v < nv) ? 1.0 : 0.0;
+                    double d = 0.0;
+#pragma unroll
+                    for (int u = 0; u < kVecUnroll; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                    acc[g0 + v] += mk * d;
                 }
             }
         }
@@ -308,47 +395,86 @@ __global__ __launch_bounds__(kThreads) void mdot_kernel(const double *__restrict
     // workgroup sums -> partials[block][i]; w.w goes to slot nv
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NG * 8 + 1; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const double s = wave_sum(acc[i]);
-        if (lane == 0) lds[wave * (NG * 8 + 1) + i] = s;
+        if (lane == 0) lds[wave * NA + i] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NG * 8 + 1) {
+    if (threadIdx.x < NA) {
         const int i = threadIdx.x;
-        const double s = ((lds[i] + lds[(NG * 8 + 1) + i]) + lds[2 * (NG * 8 + 1) + i]) + lds[3 * (NG * 8 + 1) + i];
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) s += lds[j * NA + i];
         double *row = partials + (size_t)blockIdx.x * kPartialLd;
-        if (i < nv) row[i] = s;
-        else if (i == NG * 8 && with_ww) row[nv] = s;
+        if (i < nv) publish(row + i, s);
+        else if (i == NA - 1 && with_ww) publish(row + nv, s);
     }
+    if (!arrive_last(counter, gridDim.x, &last)) return;
+    const int k = nv + (with_ww ? 1 : 0);
+    final_reduce(partials, gridDim.x, kPartialLd, k, lds);
+    if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
+    reset_counter(counter);
 }
 
-static int vec_grid(int64_t n2)
+static int vec_grid(int64_t n2, int T = kVT)
 {
-    int64_t tiles = (n2 + kVecTile2 - 1) / kVecTile2;
+    int64_t tiles = (n2 + (int64_t)T * kVecUnroll - 1) / ((int64_t)T * kVecUnroll);
     if (tiles < 1) tiles = 1;
-    return (int)(tiles < kMaxBlocks ? tiles : kMaxBlocks);
+    const int cap = T >= 512 ? kVecMaxBlocks : 2 * kVecMaxBlocks;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int T, int G, bool NT>
+static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *w,
+                        int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo, const int32_t *done)
+{
+    switch (ng) {
+    case 1: hipLaunchKernelGGL((mdot_kernel<1, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    case 2: hipLaunchKernelGGL((mdot_kernel<2, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    case 3: hipLaunchKernelGGL((mdot_kernel<3, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    default: hipLaunchKernelGGL((mdot_kernel<4, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    }
 }
 
 void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
-          double *partials, int *nblocks, const int32_t *done, hipStream_t s)
+          const Finish &f, const int32_t *done, hipStream_t s)
 {
     if (nv > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: nv=%d exceeds %d", nv, kMaxNv - 1);
+    static const int variant = env_int("SPK_MDOT_VARIANT", 3);
+    const int T = (variant == 0) ? 1024 : (variant == 4 ? 256 : 512);
     const int64_t n2 = (n + 1) / 2;
-    const int grid = vec_grid(n2);
-    *nblocks = grid;
+    const int grid = vec_grid(n2, T);
     // up to 32 vectors per launch; w.w is produced by the last launch
     int v0 = 0;
     do {
         const int cnt = (nv - v0) < 32 ? (nv - v0) : 32;
         const int last = (v0 + 32 >= nv);
         const double *Vp = V + (size_t)v0 * ldv;
-        double *pp = partials + v0;
+        double *pp = f.partials + v0;
+        double *oo = f.out + v0;
+        unsigned *cn = f.counter;
         const int ng = cnt <= 8 ? 1 : cnt <= 16 ? 2 : cnt <= 24 ? 3 : 4;
-        switch (ng) {
-        case 1: hipLaunchKernelGGL(mdot_kernel<1>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
-        case 2: hipLaunchKernelGGL(mdot_kernel<2>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
-        case 3: hipLaunchKernelGGL(mdot_kernel<3>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
-        default: hipLaunchKernelGGL(mdot_kernel<4>, dim3(grid), dim3(kThreads), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, done); break;
+        static const int nt = env_int("SPK_NT", 1);
+        if (nt) {
+            switch (variant) {
+            case 2: mdot_launch<512, 8, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            case 4: mdot_launch<256, 8, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            case 0: mdot_launch<1024, 2, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            default: mdot_launch<512, 4, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            }
+        } else {
+            switch (variant) {
+            case 2: mdot_launch<512, 8, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            case 4: mdot_launch<256, 8, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            case 0: mdot_launch<1024, 2, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            default: mdot_launch<512, 4, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+            }
         }
         v0 += 32;
     } while (v0 < nv);
@@ -359,39 +485,51 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
 // the squared norm of the updated w (first n_dot entries) is produced in the
 // same pass -> VecNorm costs no extra sweep.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void maxpy_kernel(const double *__restrict__ V, int64_t ldv,
+template <int T, int G, bool NT>
+__global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, int64_t ldv,
                                                          int nv, const int32_t *__restrict__ nv_dev,
                                                          const double *__restrict__ a, double sign,
                                                          double *__restrict__ w, int64_t n2,
                                                          int64_t n_dot, double *__restrict__ partials,
+                                                         unsigned *__restrict__ counter,
+                                                         double *__restrict__ out,
                                                          const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     if (nv_dev) nv = *nv_dev;
-    __shared__ double red[4];
+    __shared__ double red[T];
+    __shared__ int last;
     double nrm = 0.0;
-    for (int64_t tile = blockIdx.x; tile * kVecTile2 < n2; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile * (T * kVecUnroll) < n2; tile += gridDim.x) {
         double2 wv[kVecUnroll];
         int64_t idx[kVecUnroll];
         bool ok[kVecUnroll];
 #pragma unroll
         for (int u = 0; u < kVecUnroll; ++u) {
-            idx[u] = tile * kVecTile2 + u * kThreads + threadIdx.x;
+            idx[u] = tile * (T * kVecUnroll) + u * T + threadIdx.x;
             ok[u] = idx[u] < n2;
             if (!ok[u]) idx[u] = 0;
             wv[u] = ld2(w, idx[u]);
         }
-#pragma unroll 4
-        for (int i = 0; i < nv; ++i) {
-            const double ai = sign * a[i];
-            const double *Vi = V + (size_t)i * ldv;
-            double2 t[kVecUnroll];
+        // G vectors per group: their 4*G loads are all in flight before the first FMA
+        for (int g0 = 0; g0 < nv; g0 += G) {
+            double2 t[G][kVecUnroll];
+            double ai[G];
 #pragma unroll
-            for (int u = 0; u < kVecUnroll; ++u) t[u] = ld2(Vi, idx[u]);
+            for (int v = 0; v < G; ++v) {
+                const int ic = (g0 + v < nv) ? g0 + v : nv - 1;
+                ai[v] = (g0 + v < nv) ? sign * a[ic] : 0.0;
+                const double *Vi = V + (size_t)ic * ldv;
 #pragma unroll
-            for (int u = 0; u < kVecUnroll; ++u) {
-                wv[u].x += ai * t[u].x;
-                wv[u].y += ai * t[u].y;
+                for (int u = 0; u < kVecUnroll; ++u) t[v][u] = ld2s<NT>(Vi, idx[u]);
+            }
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+#pragma unroll
+                for (int u = 0; u < kVecUnroll; ++u) {
+                    wv[u].x += ai[v] * t[v][u].x;
+                    wv[u].y += ai[v] * t[v][u].y;
+                }
             }
         }
 #pragma unroll
@@ -403,21 +541,37 @@ __global__ __launch_bounds__(kThreads) void maxpy_kernel(const double *__restric
             }
         }
     }
+    if (!out) return;  // caller does not want the norm
     const double s = wave_sum(nrm);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialLd] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < T / kWave; ++j) t += red[j];
+        publish(partials + (size_t)blockIdx.x * kPartialLd, t);
+    }
+    if (!arrive_last(counter, gridDim.x, &last)) return;
+    final_reduce(partials, gridDim.x, kPartialLd, 1, red);
+    if (threadIdx.x == 0) out[0] = red[0];
+    reset_counter(counter);
 }
 
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
-           double coef_sign, double *w, int64_t n, int64_t n_dot, double *partials, int *nblocks,
+           double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
            const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n + 1) / 2;
-    const int grid = vec_grid(n2);
-    *nblocks = grid;
-    hipLaunchKernelGGL(maxpy_kernel, dim3(grid), dim3(kThreads), 0, s, V, ldv, nv, nv_dev, a, coef_sign,
-                       w, n2, n_dot, partials, done);
+    static const int T = env_int("SPK_MAXPY_T", 512), nt = env_int("SPK_NT", 1);
+    const int grid = vec_grid(n2, T);
+    static const int G = env_int("SPK_MAXPY_G", 4);
+#define SPK_MAXPY(TT, GG, NTT) hipLaunchKernelGGL((maxpy_kernel<TT, GG, NTT>), dim3(grid), dim3(TT), 0, s, V, ldv, nv, nv_dev, a, \
+                                                  coef_sign, w, n2, n_dot, f.partials, f.counter, f.out, done)
+    if (T == 512 && G == 8) { if (nt) SPK_MAXPY(512, 8, true); else SPK_MAXPY(512, 8, false); }
+    else if (T == 512) { if (nt) SPK_MAXPY(512, 4, true); else SPK_MAXPY(512, 4, false); }
+    else if (G == 2) { if (nt) SPK_MAXPY(1024, 2, true); else SPK_MAXPY(1024, 2, false); }
+    else { if (nt) SPK_MAXPY(1024, 4, true); else SPK_MAXPY(1024, 4, false); }
+#undef SPK_MAXPY
 }
 
 // ---------------------------------------------------------------------------
@@ -469,14 +623,17 @@ void axpby(double a, const double *x, double b, double *y, int64_t n, const int3
     hipLaunchKernelGGL(axpby_kernel, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, a, x, b, y, n2, done);
 }
 
-__global__ __launch_bounds__(kThreads) void sqnorm_kernel(const double *__restrict__ x, int64_t n2,
+__global__ __launch_bounds__(kVT) void sqnorm_kernel(const double *__restrict__ x, int64_t n2,
                                                           int64_t n_dot, double *__restrict__ partials,
+                                                          unsigned *__restrict__ counter,
+                                                          double *__restrict__ out,
                                                           const int32_t *__restrict__ done)
 {
     if (done && *done) return;
-    __shared__ double red[4];
+    __shared__ double red[kVT];
+    __shared__ int last;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+    for (int64_t i = (int64_t)blockIdx.x * kVT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVT) {
         const double2 v = reinterpret_cast<const double2 *>(x)[i];
         if (2 * i < n_dot) acc += v.x * v.x;
         if (2 * i + 1 < n_dot) acc += v.y * v.y;
@@ -484,14 +641,22 @@ __global__ __launch_bounds__(kThreads) void sqnorm_kernel(const double *__restri
     const double s = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialLd] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < kVWaves; ++j) t += red[j];
+        publish(partials + (size_t)blockIdx.x * kPartialLd, t);
+    }
+    if (!arrive_last(counter, gridDim.x, &last)) return;
+    final_reduce(partials, gridDim.x, kPartialLd, 1, red);
+    if (threadIdx.x == 0) out[0] = red[0];
+    reset_counter(counter);
 }
-void sqnorm(const double *x, int64_t n_dot, double *partials, int *nblocks, const int32_t *done, hipStream_t s)
+void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n_dot + 1) / 2;
     const int grid = vec_grid(n2);
-    *nblocks = grid;
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kThreads), 0, s, x, n2, n_dot, partials, done);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.counter, f.out, done);
 }
 
 __global__ __launch_bounds__(kThreads) void gather_kernel(const double *__restrict__ x,
@@ -711,13 +876,21 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t 
 
 __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
 {
-    if (threadIdx.x != 0) return;
     KrylovState *st = ka.st;
     if (st->done) return;
+    // one wave stages the column and the stored rotations in LDS (parallel loads),
+    // lane 0 then runs the dependent chain out of LDS and writes the column back once
+    __shared__ double Hc[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2];
     const int ldh = ka.ldh;
-    double *Hc = ka.H + (size_t)ldh * loc;  // column loc
+    double *Hg = ka.H + (size_t)ldh * loc;  // column loc
+    for (int j = threadIdx.x; j <= loc; j += blockDim.x) {
+        Hc[j] = dots[j];
+        ccs[j] = ka.cc[j];
+        sss[j] = ka.ss[j];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const double tt = sqrt(*nrm2);
-    for (int j = 0; j <= loc; ++j) Hc[j] = dots[j];
     // happy breakdown test
     double hapbnd = fabs(tt / ka.rs[loc]);
     if (hapbnd > 1e-30) hapbnd = 1e-30;
@@ -728,8 +901,8 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
     // previous rotations on the new column
     for (int j = 1; j <= loc; ++j) {
         const double h0 = Hc[j - 1], h1 = Hc[j];
-        Hc[j - 1] = ka.cc[j - 1] * h0 + ka.ss[j - 1] * h1;
-        Hc[j] = ka.cc[j - 1] * h1 - ka.ss[j - 1] * h0;
+        Hc[j - 1] = ccs[j - 1] * h0 + sss[j - 1] * h1;
+        Hc[j] = ccs[j - 1] * h1 - sss[j - 1] * h0;
     }
     double rnorm;
     int reason = 0;
@@ -751,6 +924,7 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
     } else {
         rnorm = 0.0;
     }
+    for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hc[j];
     st->its += 1;
     st->loc_done = loc + 1;
     st->rnorm = rnorm;

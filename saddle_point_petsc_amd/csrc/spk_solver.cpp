@@ -26,6 +26,7 @@ void spk_ctx::ensure_scratch()
 {
     if (!partials.p) partials.alloc((size_t)k::kMaxBlocks * k::kPartialLd);
     if (!small.p) small.alloc(512);
+    if (!counters.p) counters.alloc(16);
     if (!y1tmp.p) y1tmp.alloc(64);
     if (!ttmp.p) ttmp.alloc(64);
 }
@@ -235,8 +236,7 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done)
     k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
     if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, y, done, s);
     if (m > 0) {
-        k::wide_dot(c->B, x, c->partials.p, done, s);
-        k::reduce_partials(c->partials.p, c->B.nwin, k::kPartialLd, m, y + nl, done, s);
+        k::wide_dot(c->B, x, c->fin(y + nl), done, s);
         c->comm->allreduce_sum(y + nl, m, s);
     }
 }
@@ -266,8 +266,7 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
         for (int r = 0; r < m; ++r) {
             const int k0 = wp[(size_t)r], k1 = wp[(size_t)c->B.nwin * m + r];
             k::scatter_row(c->B.colidx.p, c->B.val.p, k0, k1, c->dinv.p, c->tmp.p, s);
-            k::wide_dot(c->B, c->tmp.p, c->partials.p, nullptr, s);
-            k::reduce_partials(c->partials.p, c->B.nwin, k::kPartialLd, m, c->gram.p + (size_t)r * m, nullptr, s);
+            k::wide_dot(c->B, c->tmp.p, c->fin(c->gram.p + (size_t)r * m), nullptr, s);
             k::scatter_row(c->B.colidx.p, c->B.val.p, k0, k1, nullptr, c->tmp.p, s);
         }
         c->comm->allreduce_sum(c->gram.p, m * m, s);
@@ -313,8 +312,7 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
     case SPK_SCHUR_LOWER:
     default:  // FULL
         // t = B (D x0) without storing D x0
-        k::wide_dot_jacobi(c->B, x0, c->dinv.p, c->partials.p, done, s);
-        k::reduce_partials(c->partials.p, c->B.nwin, k::kPartialLd, m, c->ttmp.p, done, s);
+        k::wide_dot_jacobi(c->B, x0, c->dinv.p, c->fin(c->ttmp.p), done, s);
         c->comm->allreduce_sum(c->ttmp.p, m, s);
         k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
         if (c->schur_fact == SPK_SCHUR_LOWER) k::jacobi(c->dinv.p, x0, y0, nl, done, s);
@@ -371,7 +369,6 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const double *inv_tt = &c->kst.p->inv_tt;
     double *sm = c->small.p;  // [0..63] dots (+w.w), [64] norm^2, [128] ||b||^2
     double *V = c->V.p, *Z = c->Z.p;
-    int nb = 0;
     auto Vj = [&](int j) { return V + (size_t)ld * j; };
     auto Zj = [&](int j) { return Z + (size_t)ld * j; };
 
@@ -379,8 +376,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const auto t0 = std::chrono::steady_clock::now();
 
     // ||b|| for KSPConvergedDefault
-    k::sqnorm(b, n_dot, c->partials.p, &nb, nullptr, s);
-    k::reduce_partials(c->partials.p, nb, k::kPartialLd, 1, sm + 128, nullptr, s);
+    k::sqnorm(b, n_dot, c->fin(sm + 128), nullptr, s);
     c->comm->allreduce_sum(sm + 128, 1, s);
     k::krylov_init(c->ka, o, sm + 128, s);
 
@@ -398,8 +394,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     int cycles = 0;
     for (;;) {
         // ---- cycle start: ||r||, convergence test, v0 = r/||r|| ----
-        k::sqnorm(Vj(0), n_dot, c->partials.p, &nb, done, s);
-        k::reduce_partials(c->partials.p, nb, k::kPartialLd, 1, sm + 64, done, s);
+        k::sqnorm(Vj(0), n_dot, c->fin(sm + 64), done, s);
         c->comm->allreduce_sum(sm + 64, 1, s);
         k::krylov_cycle_begin(c->ka, sm + 64, s);
         k::scale_dev(Vj(0), N, inv_tt, done, s);
@@ -410,11 +405,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
             op_mult(c, Zj(loc), w, done);            // w = K z_j
             // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 in the same pass)
-            k::mdot(V, ld, loc + 1, w, N, n_dot, c->partials.p, &nb, done, s);
-            k::reduce_partials(c->partials.p, nb, k::kPartialLd, loc + 2, sm, done, s);
+            k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm), done, s);
             c->comm->allreduce_sum(sm, loc + 2, s);
-            k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->partials.p, &nb, done, s);
-            k::reduce_partials(c->partials.p, nb, k::kPartialLd, 1, sm + 64, done, s);
+            k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s);
             c->comm->allreduce_sum(sm + 64, 1, s);
             // Hessenberg column, Givens, convergence -- on the device
             k::krylov_givens(c->ka, loc, sm, sm + 64, s);
@@ -427,7 +420,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         }
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
         k::krylov_cycle_end(c->ka, s);
-        k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->partials.p, &nb, nullptr, s);
+        k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);
         k::axpby(1.0, b, 0.0, Vj(0), N, done, s);

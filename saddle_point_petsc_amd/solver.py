@@ -192,6 +192,15 @@ class Context:
         return ms.value
 
 
+def _time_kernel(self, which, nv=0, warmup=5, reps=50):
+    ms = C.c_double()
+    self._chk(lib.spk_time_kernel(self.h, which.encode(), nv, warmup, reps, C.byref(ms)))
+    return ms.value
+
+
+Context.time_kernel = _time_kernel
+
+
 def _mat(A):
     m = MatCSR()
     m.row_begin, m.nrows_local, m.ncols_global = A.row_begin, A.nrows, A.ncols
