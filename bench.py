@@ -64,17 +64,21 @@ def spmv_bytes(nrows, nnz):
     return 12 * nnz + 4 * (nrows + 1) + 16 * nrows
 
 
-def iteration_bytes(n, nnz, nnzB, restart):
-    """Algorithmic bytes of ONE average FGMRES(restart) iteration of this
-    implementation on the saddle system with the full Schur PC:
-    SpMV on A (+ B^T fused) + B products + Gram-Schmidt + PC streams."""
+def iteration_bytes(n, nnz, nnzB, restart, m=4):
+    """Algorithmic bytes of ONE average FGMRES(restart) iteration of the fused
+    Schur path, vec = 8n bytes, j_avg basis vectors:
+      fused scale+PC : w', dinv, m rows of B D in; v, z, c out      (5 + m) vec
+      SpMV (y += Ax) : 12 nnz + 4 n + x + y in + y out
+      MDot           : V_0..V_j and w                               (j + 2) vec
+      MAXPY + norms  : V_0..V_j, w in/out, m rows of B D            (j + 3 + m) vec
+      per cycle      : x += Z y, true residual (unfused K x, 3 vec) / restart"""
+    vec = 8 * n
     j_avg = (restart - 1) / 2.0
-    spmv = spmv_bytes(n, nnz) + 12 * nnzB + 4 * n            # A stream + B^T rows fused in
-    bdots = 2 * (12 * nnzB + 8 * n) + 8 * n                   # B z0 and B (D x0) (+ dinv)
-    gs = ((j_avg + 2) + (j_avg + 3)) * 8 * n + 2 * 8 * n      # mdot, maxpy(+norm), scale
-    pc = (12 * nnzB + 4 * n) + 3 * 8 * n                      # bt_update: B^T rows, dinv, x0, z0
-    upd = (restart + 2 + 4) * 8 * n / restart + spmv / restart  # x += Z y, true residual, per cycle
-    return spmv + bdots + gs + pc + upd
+    spmv = spmv_bytes(n, nnz) + vec
+    fused_pc = (5 + m) * vec
+    gs = (j_avg + 2) * vec + (j_avg + 3 + m) * vec
+    cycle = (restart + 2) * vec + (spmv_bytes(n, nnz) + 2 * (12 * nnzB) + 4 * n + vec) + 3 * vec
+    return spmv + fused_pc + gs + cycle / restart
 
 
 def main():

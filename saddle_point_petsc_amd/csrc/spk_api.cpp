@@ -49,7 +49,7 @@ void spk_default_opts(spk_opts *o)
     o->guess_nonzero = 0;
     o->orthog = SPK_ORTHOG_CGS;
     o->check_every = 0;
-    o->fused = 0;
+    o->fused = 1;
 }
 
 int spk_create(spk_ctx **out, int device)

@@ -159,9 +159,18 @@ struct Finish {
     double *out;
 };
 
-// y = A x  (+ Bt-rows * lam when bt != nullptr); CSR stream kernel
+// m-vector bookkeeping of the fused Schur path (all pointers: device memory)
+struct SchurPrep {
+    int m, fact;            // m = 0 disables
+    const double *w1;       // lambda part of the un-normalised new basis vector
+    const double *traw;     // B D w' (reduced)
+    const double *shat, *gram;
+    double *y1, *x1, *w1next;
+};
+
+// y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-          const int32_t *done, hipStream_t s);
+          const int32_t *done, hipStream_t s, bool accumulate = false);
 // y[rows[i]] += Ao_row_i . xg   (compressed off-rank block)
 void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
                   const int32_t *done, hipStream_t s);
@@ -180,9 +189,15 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
           const Finish &f, const int32_t *done, hipStream_t s);
 // w += sign * sum_i a[i] * V_i ; f.out[0] = ||w_new||^2 over the first n_dot entries
 // (f.out == nullptr: no norm)
+// with bd != nullptr also f.out[1+r] = sum_i bd[i*MP + r] * w_new[i], i < n_bd (fused Schur path)
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
-           const int32_t *done, hipStream_t s);
+           const int32_t *done, hipStream_t s, const double *bd = nullptr, int64_t ldb = 0, int64_t n_bd = 0, int m = 0);
+void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *bd, hipStream_t s);
+void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
+               const Finish &f, const int32_t *done, hipStream_t s);
+void fused_scale_pc(double *v, const double *inv_tt, const double *dinv, const double *bd, int64_t ldb,
+                    const SchurPrep &p, int64_t nl, double *z, double *c, const int32_t *done, hipStream_t s);
 // x *= *alpha_dev
 void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s);
 // y = a*x + b*y with host scalars (b = 0: y = a*x without reading y)
@@ -210,8 +225,9 @@ struct KrylovArrays {
     int32_t hist_cap, ldh;
 };
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s);
-void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, const SchurPrep &prep, hipStream_t s);
+void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2,
+                   const SchurPrep &prep, hipStream_t s);
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
 }  // namespace k
 
@@ -250,6 +266,7 @@ struct spk_ctx {
     int pc_type = SPK_PC_NONE, schur_fact = SPK_SCHUR_FULL;
     bool pc_ready = false;
     spk::DevBuf<double> dinv, shat, gram;  // n_local, m, m*m
+    spk::DevBuf<double> bd;                // the m rows of B D as dense vectors of stride ld (fused Schur path)
 
     // scratch
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd

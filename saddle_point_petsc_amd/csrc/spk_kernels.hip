@@ -25,8 +25,6 @@ namespace k {
 
 constexpr int kThreads = 256;
 constexpr int kWave = 64;
-constexpr int kTileNnz = 4096;   // products staged in LDS per workgroup: 32 KiB
-constexpr int kTileRows = 256;   // rows per tile <= threads
 // Reducing vector kernels run 1024-thread workgroups on a grid of <= 256 (one per
 // CU): the "last workgroup finishes" protocol costs one same-address atomic per
 // workgroup (~12 ns each, serialised), so few fat workgroups beat many thin ones.
@@ -43,6 +41,34 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
     return v;
+}
+
+// streamed-once operands: non-temporal 16-byte loads (global_load_dwordx4 ... nt);
+// measured +9 % on the Krylov basis streams (5.25 -> 5.7 TB/s)
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ double2 ld2s(const double *p, int64_t i2)
+{
+    if (NT) {
+        const dbl2v v = __builtin_nontemporal_load(reinterpret_cast<const dbl2v *>(p) + i2);
+        double2 r;
+        r.x = v.x;
+        r.y = v.y;
+        return r;
+    }
+    return reinterpret_cast<const double2 *>(p)[i2];
+}
+template <bool NT>
+__device__ __forceinline__ int4 ld4i(const int32_t *p)
+{
+    if (NT) {
+        const int4v v = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p));
+        int4 r;
+        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+        return r;
+    }
+    return *reinterpret_cast<const int4 *>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -119,8 +145,19 @@ __device__ __forceinline__ void reset_counter(unsigned *counter)
 // the same order and roundings as a sequential CSR loop.
 // Arrays are padded by >= 8 entries so whole quads can be loaded unguarded.
 // ---------------------------------------------------------------------------
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// nnz per tile / threads per workgroup of the stream kernel (tunable for experiments)
+static int spmv_tile_nnz() { static const int t = env_int("SPK_SPMV_TILE", 2048); return t; }
+static int spmv_threads() { static const int t = env_int("SPK_SPMV_T", 256); return t; }
+
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row)
 {
+    const int kTileNnz = spmv_tile_nnz(), kTileRows = spmv_threads();
     tile_row.clear();
     tile_row.push_back(0);
     int32_t r = 0;
@@ -133,12 +170,13 @@ void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &til
     }
 }
 
-__global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
+template <bool NT, int TILE, int T>
+__global__ __launch_bounds__(T) void spmv_stream_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
     const double *__restrict__ val, const int32_t *__restrict__ tile_row, int ntiles,
     int tiles_per_xcd, const double *__restrict__ x, double *__restrict__ y,
     const int32_t *__restrict__ bt_rowptr, const int32_t *__restrict__ bt_colidx,
-    const double *__restrict__ bt_val, const double *__restrict__ lam,
+    const double *__restrict__ bt_val, const double *__restrict__ lam, int accumulate,
     const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -147,46 +185,48 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || t >= ntiles) return;
 
-    __shared__ double prod[kTileNnz + 8];
+    __shared__ double prod[TILE + 8];
     const int r0 = tile_row[t], r1 = tile_row[t + 1];
     const int nz0 = rowptr[r0], nz1 = rowptr[r1];
     const int a0 = nz0 & ~3;
     const int cnt = nz1 - a0;
 
-    if (cnt > kTileNnz) {
+    if (cnt > TILE) {
         // a single row longer than a tile: strided partial sums + block reduce
         double acc[1] = {0.0};
-        for (int k = nz0 + threadIdx.x; k < nz1; k += kThreads) acc[0] += val[k] * x[colidx[k]];
+        for (int k = nz0 + threadIdx.x; k < nz1; k += T) acc[0] += val[k] * x[colidx[k]];
         double out1;
-        __shared__ double red[4];
+        __shared__ double red[T / 64];
         const double s = wave_sum(acc[0]);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
-            out1 = ((red[0] + red[1]) + red[2]) + red[3];
+            out1 = 0.0;
+            for (int j = 0; j < T / 64; ++j) out1 += red[j];
             if (bt_rowptr)
                 for (int k = bt_rowptr[r0]; k < bt_rowptr[r0 + 1]; ++k) out1 += bt_val[k] * lam[bt_colidx[k]];
+            if (accumulate) out1 += y[r0];
             y[r0] = out1;
         }
         return;
     }
 
     // phase 1: issue every load of the tile first, then gather x, then stage.
-    constexpr int kSteps = kTileNnz / (kThreads * 4);  // 4
+    constexpr int kSteps = TILE / (T * 4);
     int4 c[kSteps];
     double2 v0[kSteps], v1[kSteps];
 #pragma unroll
     for (int i = 0; i < kSteps; ++i) {
-        const int q = (i * kThreads + threadIdx.x) * 4;
+        const int q = (i * T + threadIdx.x) * 4;
         if (q < cnt) {
-            c[i] = *reinterpret_cast<const int4 *>(colidx + a0 + q);
-            v0[i] = *reinterpret_cast<const double2 *>(val + a0 + q);
-            v1[i] = *reinterpret_cast<const double2 *>(val + a0 + q + 2);
+            c[i] = ld4i<NT>(colidx + a0 + q);
+            v0[i] = ld2s<NT>(val + a0 + q, 0);
+            v1[i] = ld2s<NT>(val + a0 + q + 2, 0);
         }
     }
 #pragma unroll
     for (int i = 0; i < kSteps; ++i) {
-        const int q = (i * kThreads + threadIdx.x) * 4;
+        const int q = (i * T + threadIdx.x) * 4;
         if (q < cnt) {
             double2 p0, p1;
             p0.x = v0[i].x * x[c[i].x];
@@ -207,19 +247,34 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
         for (int k = k0; k < k1; ++k) s += prod[k];
         if (bt_rowptr)
             for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
+        if (accumulate) s += y[r];  // y pre-loaded with B^T lambda by the fused PC kernel
         y[r] = s;
     }
 }
 
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-          const int32_t *done, hipStream_t s)
+          const int32_t *done, hipStream_t s, bool accumulate)
 {
     if (A.nrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
-    hipLaunchKernelGGL(spmv_stream_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p,
-                       A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y,
-                       bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr,
-                       bt ? bt->val.p : nullptr, lam, done);
+    static const int nt = env_int("SPK_SPMV_NT", 0);
+#define SPK_SPMV(TILE, T) if (nt) SPK_SPMV_(true, TILE, T); else SPK_SPMV_(false, TILE, T)
+#define SPK_SPMV_(NT, TILE, T) hipLaunchKernelGGL((spmv_stream_kernel<NT, TILE, T>), dim3(tpx * 8), dim3(T), 0, s, A.rowptr.p, \
+                                             A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y,                  \
+                                             bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr,                \
+                                             bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done)
+    const int tile = spmv_tile_nnz(), T = spmv_threads();
+    if (tile == 4096 && T == 256) { SPK_SPMV(4096, 256); }
+    else if (tile == 2048 && T == 256) { SPK_SPMV(2048, 256); }
+    else if (tile == 1024 && T == 256) { SPK_SPMV(1024, 256); }
+    else if (tile == 2048 && T == 128) { SPK_SPMV(2048, 128); }
+    else if (tile == 1024 && T == 128) { SPK_SPMV(1024, 128); }
+    else if (tile == 1024 && T == 64) { SPK_SPMV(1024, 64); }
+    else if (tile == 512 && T == 128) { SPK_SPMV(512, 128); }
+    else if (tile == 512 && T == 64) { SPK_SPMV(512, 64); }
+    else fail(SPK_ERR_ARG, "unsupported SPK_SPMV_TILE/SPK_SPMV_T combination %d/%d", tile, T);
+#undef SPK_SPMV
+#undef SPK_SPMV_
 }
 
 // compressed off-rank block: few short rows, one thread per row
@@ -319,20 +374,7 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t i2)
 {
     return reinterpret_cast<const double2 *>(p)[i2];
 }
-typedef double dbl2v __attribute__((ext_vector_type(2)));
-// streamed-once operand: non-temporal 16-byte load (global_load_dwordx4 ... nt)
-template <bool NT>
-__device__ __forceinline__ double2 ld2s(const double *p, int64_t i2)
-{
-    if (NT) {
-        const dbl2v v = __builtin_nontemporal_load(reinterpret_cast<const dbl2v *>(p) + i2);
-        double2 r;
-        r.x = v.x;
-        r.y = v.y;
-        return r;
-    }
-    return reinterpret_cast<const double2 *>(p)[i2];
-}
+
 
 // T threads per workgroup, G vectors loaded together (their 4*G 16-byte loads per
 // thread are all issued before the first FMA: the bytes in flight, not the
@@ -424,12 +466,6 @@ static int vec_grid(int64_t n2, int T = kVT)
     return (int)(tiles < cap ? tiles : cap);
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int T, int G, bool NT>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *w,
                         int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo, const int32_t *done)
@@ -485,7 +521,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
 // the squared norm of the updated w (first n_dot entries) is produced in the
 // same pass -> VecNorm costs no extra sweep.
 // ---------------------------------------------------------------------------
-template <int T, int G, bool NT>
+template <int T, int G, bool NT, int MP>
 __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, int64_t ldv,
                                                          int nv, const int32_t *__restrict__ nv_dev,
                                                          const double *__restrict__ a, double sign,
@@ -493,13 +529,19 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          int64_t n_dot, double *__restrict__ partials,
                                                          unsigned *__restrict__ counter,
                                                          double *__restrict__ out,
+                                                         const double *__restrict__ bd, int64_t ldb,
+                                                         int64_t n_bd, int m,
                                                          const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     if (nv_dev) nv = *nv_dev;
-    __shared__ double red[T];
+    constexpr int NR = MP + 1, W = T / kWave;
+    __shared__ double red[(W * NR > T) ? W * NR : T];
     __shared__ int last;
     double nrm = 0.0;
+    double tacc[MP > 0 ? MP : 1];
+#pragma unroll
+    for (int r = 0; r < (MP > 0 ? MP : 1); ++r) tacc[r] = 0.0;
     for (int64_t tile = blockIdx.x; tile * (T * kVecUnroll) < n2; tile += gridDim.x) {
         double2 wv[kVecUnroll];
         int64_t idx[kVecUnroll];
@@ -540,37 +582,64 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                 if (2 * idx[u] + 1 < n_dot) nrm += wv[u].y * wv[u].y;
             }
         }
+        if (MP > 0) {
+            // traw[r] += (B D)_r . w_new over the u rows; B D is stored PLANAR (row r = one dense
+            // vector of stride ldb), so these are m more perfectly coalesced streams
+#pragma unroll
+            for (int r = 0; r < MP; ++r) {
+                if (r < m) {
+                    double2 e[kVecUnroll];
+#pragma unroll
+                    for (int u = 0; u < kVecUnroll; ++u) e[u] = ld2s<NT>(bd + (size_t)r * ldb, idx[u]);
+#pragma unroll
+                    for (int u = 0; u < kVecUnroll; ++u) {
+                        if (ok[u]) {
+                            if (2 * idx[u] < n_bd) tacc[r] += e[u].x * wv[u].x;
+                            if (2 * idx[u] + 1 < n_bd) tacc[r] += e[u].y * wv[u].y;
+                        }
+                    }
+                }
+            }
+        }
     }
     if (!out) return;  // caller does not want the norm
-    const double s = wave_sum(nrm);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const double s = wave_sum(nrm);
+        if (lane == 0) red[wave * NR] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < MP; ++r) {
+        const double s = wave_sum(tacc[r]);
+        if (lane == 0) red[wave * NR + 1 + r] = s;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < NR) {
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < T / kWave; ++j) t += red[j];
-        publish(partials + (size_t)blockIdx.x * kPartialLd, t);
+        for (int j = 0; j < W; ++j) t += red[j * NR + threadIdx.x];
+        if ((int)threadIdx.x <= m) publish(partials + (size_t)blockIdx.x * kPartialLd + threadIdx.x, t);
     }
     if (!arrive_last(counter, gridDim.x, &last)) return;
-    final_reduce(partials, gridDim.x, kPartialLd, 1, red);
-    if (threadIdx.x == 0) out[0] = red[0];
+    const int k = 1 + (MP > 0 ? m : 0);
+    final_reduce(partials, gridDim.x, kPartialLd, k, red);
+    if ((int)threadIdx.x < k) out[threadIdx.x] = red[threadIdx.x];
     reset_counter(counter);
 }
 
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
-           const int32_t *done, hipStream_t s)
+           const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m)
 {
     const int64_t n2 = (n + 1) / 2;
-    static const int T = env_int("SPK_MAXPY_T", 512), nt = env_int("SPK_NT", 1);
+    constexpr int T = 512, G = 4;
     const int grid = vec_grid(n2, T);
-    static const int G = env_int("SPK_MAXPY_G", 4);
-#define SPK_MAXPY(TT, GG, NTT) hipLaunchKernelGGL((maxpy_kernel<TT, GG, NTT>), dim3(grid), dim3(TT), 0, s, V, ldv, nv, nv_dev, a, \
-                                                  coef_sign, w, n2, n_dot, f.partials, f.counter, f.out, done)
-    if (T == 512 && G == 8) { if (nt) SPK_MAXPY(512, 8, true); else SPK_MAXPY(512, 8, false); }
-    else if (T == 512) { if (nt) SPK_MAXPY(512, 4, true); else SPK_MAXPY(512, 4, false); }
-    else if (G == 2) { if (nt) SPK_MAXPY(1024, 2, true); else SPK_MAXPY(1024, 2, false); }
-    else { if (nt) SPK_MAXPY(1024, 4, true); else SPK_MAXPY(1024, 4, false); }
+    const int mp = (bd && m > 0) ? (m <= 4 ? 4 : 8) : 0;
+#define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, G, true, MPP>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
+                                          coef_sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, done)
+    if (mp == 4) SPK_MAXPY(4);
+    else if (mp == 8) SPK_MAXPY(8);
+    else SPK_MAXPY(0);
 #undef SPK_MAXPY
 }
 
@@ -793,6 +862,146 @@ void scatter_row(const int32_t *colidx, const double *val, int k0, int k1, const
                        colidx, val, k0, k1, dinv, dense);
 }
 
+// bd[r*ldb + i] = dinv_i * B_ri : the m rows of B D as dense vectors (planar; zero where B has no entry)
+__global__ __launch_bounds__(kThreads) void build_bd_kernel(const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ colidx,
+                                                            const double *__restrict__ val, int nrows,
+                                                            const double *__restrict__ dinv, int m, int64_t ldb,
+                                                            double *__restrict__ bd)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= nrows) return;
+    for (int r = 0; r < m; ++r) bd[(size_t)r * ldb + i] = 0.0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) bd[(size_t)colidx[k] * ldb + i] += val[k] * dinv[i];
+}
+void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *bd, hipStream_t s)
+{
+    if (Bt.nrows == 0) return;
+    hipLaunchKernelGGL(build_bd_kernel, dim3((Bt.nrows + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       Bt.rowptr.p, Bt.colidx.p, Bt.val.p, Bt.nrows, dinv, m, ldb, bd);
+}
+
+// out[0] = r.r (first n_dot entries), out[1+q] = sum_i (B D)[i][q] r_i : cycle start of the fused path
+template <int MP>
+__global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict__ x, int64_t n2, int64_t n_dot,
+                                                        const double *__restrict__ bd, int64_t ldb, int64_t n_bd,
+                                                        int m, double *__restrict__ partials,
+                                                        unsigned *__restrict__ counter, double *__restrict__ out,
+                                                        const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr int T = 512, NR = MP + 1, W = T / kWave;
+    __shared__ double red[(W * NR > T) ? W * NR : T];
+    __shared__ int last;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < n2; i += (int64_t)gridDim.x * T) {
+        const double2 v = reinterpret_cast<const double2 *>(x)[i];
+        if (2 * i < n_dot) acc[0] += v.x * v.x;
+        if (2 * i + 1 < n_dot) acc[0] += v.y * v.y;
+#pragma unroll
+        for (int r = 0; r < MP; ++r) {
+            if (r < m) {
+                const double2 e = reinterpret_cast<const double2 *>(bd + (size_t)r * ldb)[i];
+                if (2 * i < n_bd) acc[1 + r] += e.x * v.x;
+                if (2 * i + 1 < n_bd) acc[1 + r] += e.y * v.y;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double s = wave_sum(acc[r]);
+        if (lane == 0) red[wave * NR + r] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NR) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) t += red[j * NR + threadIdx.x];
+        if ((int)threadIdx.x <= m) publish(partials + (size_t)blockIdx.x * kPartialLd + threadIdx.x, t);
+    }
+    if (!arrive_last(counter, gridDim.x, &last)) return;
+    final_reduce(partials, gridDim.x, kPartialLd, 1 + m, red);
+    if ((int)threadIdx.x < 1 + m) out[threadIdx.x] = red[threadIdx.x];
+    reset_counter(counter);
+}
+void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
+               const Finish &f, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = vec_grid(n2, 512);
+    if (m <= 4)
+        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, f.partials, f.counter, f.out, done);
+    else
+        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, f.partials, f.counter, f.out, done);
+}
+
+// Fused "normalise + Schur preconditioner + B^T part of the operator" (one pass):
+//   v  = w' * inv_tt                          (VecScale of the new basis vector, in place)
+//   z0 = D v - (B D)^T y1   (FULL)  |  D v    (LOWER)       -> Z_j
+//   c  = B^T y1 = ((B D)^T y1) ./ dinv                      -> pre-load of the SpMV output
+// lambda parts (m values) are written by the first workgroup.
+template <int MP>
+__global__ __launch_bounds__(kThreads) void fused_scale_pc_kernel(
+    double *__restrict__ v, const double *__restrict__ inv_tt_p, const double *__restrict__ dinv,
+    const double *__restrict__ bd, int64_t ldb, const double *__restrict__ y1, const double *__restrict__ x1,
+    const double *__restrict__ w1next, int fact, int64_t nl, int m, double *__restrict__ z,
+    double *__restrict__ c, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const double inv_tt = *inv_tt_p;
+    double yv[MP];
+#pragma unroll
+    for (int r = 0; r < MP; ++r) yv[r] = r < m ? y1[r] : 0.0;
+    const int64_t n2 = nl / 2;  // nl is even on this path (checked by the host)
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+        double2 w = reinterpret_cast<double2 *>(v)[i];
+        const double2 d = reinterpret_cast<const double2 *>(dinv)[i];
+        w.x *= inv_tt;
+        w.y *= inv_tt;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < MP; ++r) {
+            if (r < m) {
+                const double2 e = ld2s<true>(bd + (size_t)r * ldb, i);
+                s0 += e.x * yv[r];
+                s1 += e.y * yv[r];
+            }
+        }
+        double2 zz, cc;
+        zz.x = w.x * d.x;
+        zz.y = w.y * d.y;
+        if (fact == SPK_SCHUR_FULL) {
+            zz.x -= s0;
+            zz.y -= s1;
+        }
+        cc.x = s0 / d.x;
+        cc.y = s1 / d.y;
+        reinterpret_cast<double2 *>(v)[i] = w;
+        reinterpret_cast<double2 *>(z)[i] = zz;
+        reinterpret_cast<double2 *>(c)[i] = cc;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < m) {
+        v[nl + threadIdx.x] = x1[threadIdx.x];
+        z[nl + threadIdx.x] = y1[threadIdx.x];
+        c[nl + threadIdx.x] = w1next[threadIdx.x];
+    }
+}
+void fused_scale_pc(double *v, const double *inv_tt, const double *dinv, const double *bd, int64_t ldb,
+                    const SchurPrep &p, int64_t nl, double *z, double *c, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = nl / 2;
+    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
+    if (p.m <= 4)
+        hipLaunchKernelGGL(fused_scale_pc_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, inv_tt, dinv, bd, ldb,
+                           p.y1, p.x1, p.w1next, p.fact, nl, p.m, z, c, done);
+    else
+        hipLaunchKernelGGL(fused_scale_pc_kernel<8>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, inv_tt, dinv, bd, ldb,
+                           p.y1, p.x1, p.w1next, p.fact, nl, p.m, z, c, done);
+}
+
 __global__ void sum_slots_kernel(const double *__restrict__ slots, int nslots, int ld, int count,
                                  double *__restrict__ out)
 {
@@ -821,6 +1030,33 @@ __device__ __forceinline__ int converged_default(double rnorm, const KrylovState
     return 0;
 }
 
+// Fused Schur path: right after the norm of the new basis vector is known, one
+// thread prepares the m-vector data of the NEXT preconditioner/operator apply:
+//   x1 = lambda part of v = w'/||w'||,   t = B D v = traw/||w'||,
+//   y1 = -(x1 - t)/S^                    (LOWER / FULL, S~ = -S^)
+//   w1 = B z0 = t - G y1 (FULL) | t (LOWER)   with G = B D B^T (m x m)
+// Called by the whole (single-wave) workgroup; lane r < m owns constraint r.
+__device__ __forceinline__ void schur_prepare(const SchurPrep &p, double inv_tt, double *y1_lds)
+{
+    const int r = threadIdx.x;
+    double t = 0.0;
+    if (r < p.m) {
+        const double x1 = p.w1[r] * inv_tt;
+        t = p.traw[r] * inv_tt;
+        const double y = -(x1 - t) / p.shat[r];
+        p.x1[r] = x1;
+        p.y1[r] = y;
+        y1_lds[r] = y;
+    }
+    __syncthreads();
+    if (r < p.m) {
+        double w = t;
+        if (p.fact == SPK_SCHUR_FULL)
+            for (int q = 0; q < p.m; ++q) w -= p.gram[r * p.m + q] * y1_lds[q];
+        p.w1next[r] = w;
+    }
+}
+
 __global__ void krylov_init_kernel(KrylovArrays ka, spk_opts o, const double *bnorm2)
 {
     if (threadIdx.x != 0) return;
@@ -846,35 +1082,45 @@ void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2
     hipLaunchKernelGGL(krylov_init_kernel, dim3(1), dim3(64), 0, s, ka, o, bnorm2);
 }
 
-__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2)
+__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, SchurPrep prep)
 {
-    if (threadIdx.x != 0) return;
+    __shared__ double bc[2];
+    __shared__ double y1s[16];
     KrylovState *st = ka.st;
-    st->loc_done = 0;
-    if (st->done) return;
-    const double rnorm = sqrt(*nrm2);
-    st->rnorm = rnorm;
-    if (st->its == 0) {
-        st->rnorm0 = rnorm;
-        if (ka.hist_cap > 0) ka.hist[0] = rnorm;
+    if (threadIdx.x == 0) {
+        bc[0] = 0.0;  // 1.0 -> run the Schur preparation
+        st->loc_done = 0;
+        if (!st->done) {
+            const double rnorm = sqrt(*nrm2);
+            st->rnorm = rnorm;
+            if (st->its == 0) {
+                st->rnorm0 = rnorm;
+                if (ka.hist_cap > 0) ka.hist[0] = rnorm;
+            }
+            int reason = converged_default(rnorm, st);
+            if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
+            st->reason = reason;
+            st->hapend = 0;
+            if (reason) {
+                st->done = 1;
+            } else {
+                ka.rs[0] = rnorm;
+                st->inv_tt = 1.0 / rnorm;
+                bc[0] = 1.0;
+                bc[1] = 1.0 / rnorm;
+            }
+        }
     }
-    int reason = converged_default(rnorm, st);
-    if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
-    st->reason = reason;
-    st->hapend = 0;
-    if (reason) {
-        st->done = 1;
-        return;
-    }
-    ka.rs[0] = rnorm;
-    st->inv_tt = 1.0 / rnorm;
+    __syncthreads();
+    if (prep.m > 0 && bc[0] != 0.0) schur_prepare(prep, bc[1], y1s);
 }
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s)
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, const SchurPrep &prep, hipStream_t s)
 {
-    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2);
+    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, prep);
 }
 
-__global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
+__global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2,
+                                     SchurPrep prep)
 {
     KrylovState *st = ka.st;
     if (st->done) return;
@@ -888,8 +1134,11 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
         ccs[j] = ka.cc[j];
         sss[j] = ka.ss[j];
     }
+    __shared__ double bc[2];
+    __shared__ double y1s[16];
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x == 0) bc[0] = 0.0;
+    if (threadIdx.x == 0) [&]() {
     const double tt = sqrt(*nrm2);
     // happy breakdown test
     double hapbnd = fabs(tt / ka.rs[loc]);
@@ -935,10 +1184,18 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
     if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
     st->reason = reason;
     if (reason) st->done = 1;
+    else {
+        bc[0] = 1.0;
+        bc[1] = st->inv_tt;
+    }
+    }();
+    __syncthreads();
+    if (prep.m > 0 && bc[0] != 0.0) schur_prepare(prep, bc[1], y1s);
 }
-void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s)
+void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2,
+                   const SchurPrep &prep, hipStream_t s)
 {
-    hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2);
+    hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2, prep);
 }
 
 // back substitution for the loc_done columns built in this cycle

@@ -276,6 +276,13 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
         for (int r = 0; r < m; ++r) sh[(size_t)r] = G[(size_t)r * m + r];
         SPK_HIP(hipMemcpy(c->shat.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // dense rows of B D for the fused path (Schur LOWER/FULL, even local size)
+    c->bd.release();
+    if (pc_type == SPK_PC_SCHUR && m > 0 && (schur_fact == SPK_SCHUR_FULL || schur_fact == SPK_SCHUR_LOWER) &&
+        c->n_local % 2 == 0) {
+        c->bd.alloc((size_t)c->ld * m, 16);
+        k::build_bd(c->Bt, c->dinv.p, m, c->ld, c->bd.p, s);
+    }
     SPK_HIP(hipStreamSynchronize(s));
     c->pc_type = pc_type;
     c->schur_fact = schur_fact;
@@ -390,28 +397,61 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, nullptr, s);
     }
 
+    // fused Schur path: PC + B^T part of the operator + VecScale in one pass, B D w' in the maxpy pass
+    const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR;
+    const int m = c->m;
+    const int32_t nl = c->n_local;
+    double *y1b = c->y1tmp.p, *x1b = c->y1tmp.p + 16, *w1b = c->y1tmp.p + 32;
+    auto prep_for = [&](const double *wvec) {
+        k::SchurPrep p{};
+        p.m = fused ? m : 0;
+        p.fact = c->schur_fact;
+        p.w1 = wvec + nl;
+        p.traw = sm + 65;
+        p.shat = c->shat.p;
+        p.gram = c->gram.p;
+        p.y1 = y1b;
+        p.x1 = x1b;
+        p.w1next = w1b;
+        return p;
+    };
+
     KrylovState st{};
     int cycles = 0;
     for (;;) {
         // ---- cycle start: ||r||, convergence test, v0 = r/||r|| ----
-        k::sqnorm(Vj(0), n_dot, c->fin(sm + 64), done, s);
-        c->comm->allreduce_sum(sm + 64, 1, s);
-        k::krylov_cycle_begin(c->ka, sm + 64, s);
-        k::scale_dev(Vj(0), N, inv_tt, done, s);
+        if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, c->fin(sm + 64), done, s);
+        else k::sqnorm(Vj(0), n_dot, c->fin(sm + 64), done, s);
+        c->comm->allreduce_sum(sm + 64, fused ? 1 + m : 1, s);
+        k::krylov_cycle_begin(c->ka, sm + 64, prep_for(Vj(0)), s);
+        if (!fused) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
         for (int loc = 0; loc < mk && !stop; ++loc) {
             double *w = Vj(loc + 1);
-            op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
-            op_mult(c, Zj(loc), w, done);            // w = K z_j
+            if (fused) {
+                // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part)
+                k::fused_scale_pc(Vj(loc), inv_tt, c->dinv.p, c->bd.p, ld, prep_for(Vj(loc)), nl, Zj(loc), w, done, s);
+                // w += A z0 (halo exchange inside op_mult is bypassed: do it here)
+                if (c->n_ghost > 0) {
+                    k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
+                    c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
+                }
+                k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true);
+                if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, w, done, s);
+            } else {
+                op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
+                op_mult(c, Zj(loc), w, done);            // w = K z_j
+            }
             // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 in the same pass)
             k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm), done, s);
             c->comm->allreduce_sum(sm, loc + 2, s);
-            k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s);
-            c->comm->allreduce_sum(sm + 64, 1, s);
-            // Hessenberg column, Givens, convergence -- on the device
-            k::krylov_givens(c->ka, loc, sm, sm + 64, s);
-            k::scale_dev(w, N, inv_tt, done, s);  // v_{j+1} = w / ||w||
+            if (fused) k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s, c->bd.p, ld, nl, m);
+            else k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s);
+            c->comm->allreduce_sum(sm + 64, fused ? 1 + m : 1, s);
+            // Hessenberg column, Givens, convergence (+ the next apply's m-vector data) -- on the device
+            k::krylov_givens(c->ka, loc, sm, sm + 64, prep_for(w), s);
+            if (!fused) k::scale_dev(w, N, inv_tt, done, s);  // v_{j+1} = w / ||w||
             if (o.check_every > 0 && (loc + 1) % o.check_every == 0 && loc + 1 < mk) {
                 SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
                 SPK_HIP(hipStreamSynchronize(s));

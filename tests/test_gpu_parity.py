@@ -171,6 +171,27 @@ def test_fgmres_saddle_schur(spk, oracle, golden_m32, fact):
     assert np.allclose(x[-4:], golden_m32["saddle"][-4:], rtol=1e-7)
 
 
+@pytest.mark.parametrize("fact", [1, 3])
+@pytest.mark.parametrize("mx,my", [(32, 32), (45, 18)])
+def test_fused_schur_path_equals_unfused(spk, oracle, fact, mx, my):
+    """opts.fused = 1 (default: VecScale + Schur PC + B^T product in one pass, B D w' inside
+    the MAXPY pass, w1 = t - G y1) against the step-by-step PCApply / MatMult path."""
+    A, f = spk.AssembleOperator_Laplace(mx, my)
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, fact)
+        xf, inf_ = c.fgmres(rhs, rtol=1e-10, fused=1)
+        xu, inu = c.fgmres(rhs, rtol=1e-10, fused=0)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=fact, rtol=1e-10)
+    assert inf_["reason"] == inu["reason"] == 2
+    assert abs(inf_["its"] - inu["its"]) <= 1 and abs(inf_["its"] - io["its"]) <= 1
+    assert np.allclose(inf_["history"][:21], inu["history"][:21], rtol=1e-9)
+    assert relerr(xf, xu) < 1e-8 and relerr(xf, xo) < 1e-8
+
+
 def test_fgmres_rtol_1e8_iteration_counts(spk, golden_m32):
     A, f = spk.AssembleOperator_Laplace(32)
     B, g = spk.AssembleOperator_Constraints(32)
