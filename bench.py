@@ -103,15 +103,24 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    import saddle_point_petsc_amd as S   # fails loudly if libspk.so is not built
-
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SPK_BENCH_FORCE_DIST") == "1"   # the latter: 1-GPU rehearsal
+    if use_dist:
+        # torch FIRST: its wheel carries a private libamdhip64 (DT_NEEDED "libamdhip64.so"); loaded
+        # before libspk.so, the loader resolves libspk's "libamdhip64.so.7" to that same copy by
+        # soname.  The other order maps two HIP runtimes into one process and the second one finds
+        # no device (measured: spk_create -> "no ROCm-capable device").
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import saddle_point_petsc_amd as S   # fails loudly if libspk.so is not built
 
     M = args.grid
     n, nnz_global = S.grid_sizes(M)
@@ -123,7 +132,7 @@ def main():
     if saddle:
         B, g = S.AssembleOperator_Constraints(M, M, rb, re_)
     ctx = S.Context(local_rank)
-    if world > 1:
+    if use_dist:
         ids = [S.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init_rccl(rank, world, ids[0])
