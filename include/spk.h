@@ -160,6 +160,12 @@ int spk_vec_get(spk_ctx *ctx, const double *dev, double *host, int64_t n);
 int spk_get_sizes(const spk_ctx *ctx, int64_t *n_global, int32_t *n_local, int32_t *m,
                   int64_t *nnz_local, int32_t *n_ghost);
 
+/* Storage the A-block SpMV actually streams: format 0 = CSR (12 B per stored non-zero),
+ * 1 = 2x2-blocked CSR (36 B per 4 non-zeros; chosen automatically when rows 2k, 2k+1 share
+ * their pattern and columns pair up, as for a dof-2 DMDA; SPK_SPMV_FORMAT=csr forces CSR).
+ * layout_bytes = bytes one SpMV reads and writes in that layout (matrix + x + y). */
+int spk_get_spmv_info(const spk_ctx *ctx, int32_t *format, int64_t *layout_bytes);
+
 /* ---- single kernels through the ABI (parity tests, bench.py) -------------- */
 /* h[i] = V_i . w  (i < nv), V given as nv vectors of length n with stride ldv
  * (VecMDot).  Host pointers. */

@@ -82,6 +82,20 @@ struct CsrDev {
     int32_t ntiles = 0;
 };
 
+// 2x2-blocked copy of the diagonal part of A (dof-2 DMDA matrices: rows 2k, 2k+1 share
+// their column pattern, columns come in pairs 2c, 2c+1 -- PETSc exploits the same fact
+// with BAIJ / inodes).  One int32 block column + 4 values per block: 36 B per 4 stored
+// non-zeros instead of 48.  Values are kept as two planes so every load is 16 B/lane.
+struct BcsrDev {
+    int32_t nbrows = 0;
+    int64_t nblocks = 0;
+    DevBuf<int32_t> browptr, bcol;
+    DevBuf<double> vtop, vbot;  // (a00,a01) and (a10,a11) per block
+    DevBuf<int32_t> tile_brow;
+    int32_t ntiles = 0;
+    bool ok = false;
+};
+
 // Short-and-wide block (B: m rows x n_local cols) cut into column windows so
 // that x is streamed once for all m rows.
 struct WideDev {
@@ -171,6 +185,10 @@ struct SchurPrep {
 // y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
           const int32_t *done, hipStream_t s, bool accumulate = false);
+// same product from the 2x2-blocked copy (bitwise the same sums: CSR order is kept)
+void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+               const int32_t *done, hipStream_t s, bool accumulate = false);
+void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
 // y[rows[i]] += Ao_row_i . xg   (compressed off-rank block)
 void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
                   const int32_t *done, hipStream_t s);
@@ -249,6 +267,8 @@ struct spk_ctx {
 
     // (0,0) block: diagonal part, compressed off-rank part
     spk::CsrDev Ad, Ao;
+    spk::BcsrDev Ab;               // 2x2-blocked copy of Ad when the structure allows
+    int spmv_format = 0;           // 0 = CSR stream kernel, 1 = BCSR
     spk::DevBuf<int32_t> ao_rows;  // local row of each compressed Ao row
     bool have_A = false, have_B = false;
 

@@ -277,6 +277,126 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 #undef SPK_SPMV_
 }
 
+// ---------------------------------------------------------------------------
+// 2x2-blocked stream SpMV: same structure as spmv_stream_kernel, one block (4 values,
+// one block column) per thread-step, x gathered 16 bytes at a time.  The products of a
+// block land in LDS as (a00 x0, a01 x1, a10 x0, a11 x1); row 2k adds its pairs in block
+// order = CSR order, so the result is bit-identical to the CSR kernel and the oracle.
+// ---------------------------------------------------------------------------
+constexpr int kBTile = 512;  // blocks per tile (2048 stored non-zeros)
+
+void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow)
+{
+    tile_brow.clear();
+    tile_brow.push_back(0);
+    int32_t r = 0;
+    while (r < nbrows) {
+        const int32_t r0 = r;
+        while (r < nbrows && (r - r0) < 128 && (browptr[r + 1] - browptr[r0]) <= kBTile) ++r;
+        if (r == r0) ++r;  // block row longer than a tile: handled by the strided path
+        tile_brow.push_back(r);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
+    const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
+    const double *__restrict__ vtop, const double *__restrict__ vbot,
+    const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd,
+    const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ bt_rowptr,
+    const int32_t *__restrict__ bt_colidx, const double *__restrict__ bt_val,
+    const double *__restrict__ lam, int accumulate, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    __shared__ double prod[kBTile * 4];
+    const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
+    const int b0 = browptr[br0], b1 = browptr[br1];
+    const int cnt = b1 - b0;
+
+    if (cnt > kBTile) {
+        // one very long block row: strided partial sums, tree order
+        double a0 = 0.0, a1 = 0.0;
+        for (int q = b0 + threadIdx.x; q < b1; q += kThreads) {
+            const double2 xv = reinterpret_cast<const double2 *>(x)[bcol[q]];
+            const double2 tp = reinterpret_cast<const double2 *>(vtop)[q], bo = reinterpret_cast<const double2 *>(vbot)[q];
+            a0 += tp.x * xv.x + tp.y * xv.y;
+            a1 += bo.x * xv.x + bo.y * xv.y;
+        }
+        __shared__ double red[8];
+        const double s0 = wave_sum(a0), s1 = wave_sum(a1);
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6] = s0;
+            red[4 + (threadIdx.x >> 6)] = s1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const int r = 2 * br0 + threadIdx.x;
+            double o = ((red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + red[4 * threadIdx.x + 2]) + red[4 * threadIdx.x + 3];
+            if (bt_rowptr)
+                for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) o += bt_val[k] * lam[bt_colidx[k]];
+            if (accumulate) o += y[r];
+            y[r] = o;
+        }
+        return;
+    }
+
+    constexpr int kSteps = kBTile / kThreads;  // 2
+    int c[kSteps];
+    double2 tp[kSteps], bo[kSteps];
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int q = i * kThreads + threadIdx.x;
+        if (q < cnt) {
+            c[i] = bcol[b0 + q];
+            tp[i] = reinterpret_cast<const double2 *>(vtop)[b0 + q];
+            bo[i] = reinterpret_cast<const double2 *>(vbot)[b0 + q];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int q = i * kThreads + threadIdx.x;
+        if (q < cnt) {
+            const double2 xv = reinterpret_cast<const double2 *>(x)[c[i]];
+            double2 p0, p1;
+            p0.x = tp[i].x * xv.x;
+            p0.y = tp[i].y * xv.y;
+            p1.x = bo[i].x * xv.x;
+            p1.y = bo[i].y * xv.y;
+            *reinterpret_cast<double2 *>(prod + 4 * q) = p0;
+            *reinterpret_cast<double2 *>(prod + 4 * q + 2) = p1;
+        }
+    }
+    __syncthreads();
+
+    const int lr = threadIdx.x;  // local row
+    if (lr < 2 * (br1 - br0)) {
+        const int br = br0 + (lr >> 1), half = lr & 1;
+        const int k0 = browptr[br] - b0, k1 = browptr[br + 1] - b0;
+        double s = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            const double2 p = *reinterpret_cast<const double2 *>(prod + 4 * k + 2 * half);
+            s += p.x;
+            s += p.y;
+        }
+        const int r = 2 * br0 + lr;
+        if (bt_rowptr)
+            for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
+        if (accumulate) s += y[r];
+        y[r] = s;
+    }
+}
+
+void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+               const int32_t *done, hipStream_t s, bool accumulate)
+{
+    if (A.nbrows == 0) return;
+    const int tpx = (A.ntiles + 7) / 8;
+    hipLaunchKernelGGL(spmv_bcsr_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, A.vtop.p,
+                       A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done);
+}
+
 // compressed off-rank block: few short rows, one thread per row
 __global__ __launch_bounds__(kThreads) void spmv_offdiag_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,

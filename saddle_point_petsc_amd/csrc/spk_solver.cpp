@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -91,6 +92,49 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     c->n_local = nrows_local;
     c->n_ghost = (int32_t)sp.garray.size();
     upload_csr(c->Ad, nrows_local, nrows_local, sp.d_rowptr, sp.d_colidx, sp.d_val, true);
+
+    // 2x2-blocked copy when every row pair shares its pattern and columns pair up (dof-2 grids)
+    {
+        BcsrDev &Ab = c->Ab;
+        Ab.ok = false;
+        Ab.nbrows = 0;
+        Ab.ntiles = 0;
+        bool ok = nrows_local % 2 == 0 && nrows_local > 0;
+        const auto &rp = sp.d_rowptr;
+        const auto &ci = sp.d_colidx;
+        std::vector<int32_t> brp, bcol;
+        std::vector<double> vt, vb;
+        if (ok) {
+            brp.assign(1, 0);
+            for (int32_t r = 0; ok && r < nrows_local; r += 2) {
+                const int32_t k0 = rp[r], k1 = rp[r + 1], l0 = rp[r + 1], l1 = rp[r + 2];
+                if ((k1 - k0) != (l1 - l0) || ((k1 - k0) & 1)) { ok = false; break; }
+                for (int32_t k = 0; k < k1 - k0; k += 2) {
+                    const int32_t c0 = ci[k0 + k], c1 = ci[k0 + k + 1];
+                    if ((c0 & 1) || c1 != c0 + 1 || ci[l0 + k] != c0 || ci[l0 + k + 1] != c1) { ok = false; break; }
+                    bcol.push_back(c0 >> 1);
+                    vt.push_back(sp.d_val[k0 + k]); vt.push_back(sp.d_val[k0 + k + 1]);
+                    vb.push_back(sp.d_val[l0 + k]); vb.push_back(sp.d_val[l0 + k + 1]);
+                }
+                brp.push_back((int32_t)bcol.size());
+            }
+        }
+        if (ok) {
+            Ab.nbrows = nrows_local / 2;
+            Ab.nblocks = (int64_t)bcol.size();
+            Ab.browptr.upload(brp.data(), brp.size(), 8);
+            Ab.bcol.upload(bcol.data(), bcol.size(), 16);
+            Ab.vtop.upload(vt.data(), vt.size(), 32);
+            Ab.vbot.upload(vb.data(), vb.size(), 32);
+            std::vector<int32_t> tb;
+            k::build_btiles(brp.data(), Ab.nbrows, tb);
+            Ab.ntiles = (int32_t)tb.size() - 1;
+            Ab.tile_brow.upload(tb.data(), tb.size(), 8);
+            Ab.ok = true;
+        }
+        const char *fmt = getenv("SPK_SPMV_FORMAT");
+        c->spmv_format = (Ab.ok && !(fmt && !strcmp(fmt, "csr"))) ? 1 : 0;
+    }
 
     // compress the off-rank block to the rows that have entries
     std::vector<int32_t> rows, orp(1, 0);
@@ -233,7 +277,8 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done)
         k::gather(x, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
         c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
     }
-    k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
+    if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
+    else k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
     if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, y, done, s);
     if (m > 0) {
         k::wide_dot(c->B, x, c->fin(y + nl), done, s);
@@ -437,7 +482,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
                 }
-                k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true);
+                if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true);
+                else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true);
                 if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, w, done, s);
             } else {
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j

@@ -90,6 +90,11 @@ class Context:
         lib.spk_get_sizes(self.h, C.byref(ng), C.byref(nl), C.byref(m), C.byref(nnz), C.byref(gh))
         return dict(n_global=ng.value, n_local=nl.value, m=m.value, nnz_local=nnz.value, n_ghost=gh.value)
 
+    def spmv_info(self):
+        fmt, b = C.c_int32(), C.c_int64()
+        lib.spk_get_spmv_info(self.h, C.byref(fmt), C.byref(b))
+        return dict(format={0: "csr", 1: "bcsr2x2"}[fmt.value], layout_bytes=b.value)
+
     def _n(self):
         s = self.sizes()
         return s["n_local"] + s["m"]

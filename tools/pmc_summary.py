@@ -35,10 +35,10 @@ for k in sorted(set(fe) | set(wr)):
     f, w = fe.get(k, 0.0), wr.get(k, 0.0)
     out["kernels"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
-sp = [v for k, v in out["kernels"].items() if "spmv_stream" in k]
-if sp:
-    json.dump({"hbm_bytes_per_launch": sp[0]["hbm_bytes_corrected"], "source": f"profiles/{tag}_pmc_summary.json",
-               "workload": "1024x1024 grid A-block SpMV", "fetch_kib": sp[0]["FETCH_SIZE_KiB"],
-               "write_kib": sp[0]["WRITE_SIZE_KiB"]},
-              open(os.path.join(ROOT, "profiles", "spmv_traffic.json"), "w"), indent=1)
+tr = {"source": f"profiles/{tag}_pmc_summary.json", "workload": "1024x1024 grid A-block SpMV"}
+for key, pat in (("csr", "spmv_stream"), ("bcsr2x2", "spmv_bcsr")):
+    sp = [v for k, v in out["kernels"].items() if pat in k]
+    if sp:
+        tr["hbm_bytes_per_launch_" + key] = sp[0]["hbm_bytes_corrected"]
+json.dump(tr, open(os.path.join(ROOT, "profiles", "spmv_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
