@@ -58,6 +58,8 @@ enum { SPK_PC_NONE = 0, SPK_PC_JACOBI = 1, SPK_PC_SCHUR = 2 };
 enum { SPK_SCHUR_DIAG = 0, SPK_SCHUR_LOWER = 1, SPK_SCHUR_UPPER = 2, SPK_SCHUR_FULL = 3 };
 /* -ksp_gmres_{classical,modified}gramschmidt */
 enum { SPK_ORTHOG_CGS = 0, SPK_ORTHOG_MGS = 1 };
+/* -ksp_gmres_cgs_refinement_type {never,ifneeded,always} */
+enum { SPK_REFINE_NEVER = 0, SPK_REFINE_IFNEEDED = 1, SPK_REFINE_ALWAYS = 2 };
 /* SpMV storage of the (0,0) block */
 enum { SPK_SPMV_CSR = 0 };
 
@@ -83,7 +85,8 @@ typedef struct spk_opts {
                                The iterate never depends on it.       */
     int32_t fused;          /* 1: fused PC+operator kernels where the PC allows,
                                0: PCApply and MatMult as separate steps */
-    int32_t reserved[4];
+    int32_t cgs_refine;     /* -ksp_gmres_cgs_refinement_type: SPK_REFINE_* (never) */
+    int32_t reserved[3];
 } spk_opts;
 
 typedef struct spk_result {

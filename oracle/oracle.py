@@ -40,6 +40,7 @@ class Options(C.Structure):
         ("pc_type", C.c_int32), ("schur_fact", C.c_int32), ("restart", C.c_int32),
         ("max_it", C.c_int32), ("rtol", C.c_double), ("abstol", C.c_double),
         ("dtol", C.c_double), ("guess_nonzero", C.c_int32), ("threads", C.c_int32),
+        ("orthog", C.c_int32), ("refine", C.c_int32),
     ]
 
 
@@ -199,7 +200,7 @@ def schur_setup(A, B):
 
 
 def fgmres(A, b, B=None, x0=None, pc_type=PC_JACOBI, schur_fact=SCHUR_FULL, restart=30,
-           max_it=10000, rtol=1e-5, abstol=1e-50, dtol=1e4, threads=1):
+           max_it=10000, rtol=1e-5, abstol=1e-50, dtol=1e4, threads=1, orthog=0, refine=0):
     """PETSc-semantics FGMRES on K = A or [A B^T; B 0].  Returns (x, info)."""
     op = _operator(A, B)
     N = A.nrows + (B.nrows if B is not None else 0)
@@ -207,7 +208,7 @@ def fgmres(A, b, B=None, x0=None, pc_type=PC_JACOBI, schur_fact=SCHUR_FULL, rest
     assert b.shape == (N,)
     x = np.zeros(N) if x0 is None else np.array(x0, np.float64)
     opt = Options(pc_type, schur_fact, restart, max_it, rtol, abstol, dtol,
-                  0 if x0 is None else 1, threads)
+                  0 if x0 is None else 1, threads, orthog, refine)
     res = Result()
     hist = np.zeros(max_it + 2)
     lib().spo_fgmres(C.byref(op), C.byref(opt), b, x, C.byref(res), hist, len(hist))

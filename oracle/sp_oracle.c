@@ -416,6 +416,8 @@ typedef struct {
     int32_t pc_type, schur_fact, restart, max_it;
     double rtol, abstol, dtol;
     int32_t guess_nonzero, threads;
+    int32_t orthog;  /* 0 classical (PETSc default), 1 modified Gram-Schmidt */
+    int32_t refine;  /* CGS refinement: 0 never (default), 1 ifneeded, 2 always */
 } spo_options;
 
 typedef struct {
@@ -620,10 +622,31 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
             /* z_j = M^-1 v_j ; w = K z_j */
             spo_pc_apply(&pc, VV(loc), ZZ(loc));
             spo_apply_K(op, ZZ(loc), VV(loc + 1));
-            /* classical Gram-Schmidt: VecMDot, negate, VecMAXPY */
-            for (int j = 0; j <= loc; ++j) lhh[j] = -spo_dot(N, VV(loc + 1), VV(j));
-            for (int j = 0; j <= loc; ++j) spo_axpy(N, lhh[j], VV(j), VV(loc + 1));
-            for (int j = 0; j <= loc; ++j) HH(j, loc) = -lhh[j];
+            if (opt->orthog == 1) {
+                /* KSPGMRESModifiedGramSchmidtOrthogonalization: VecDot / VecAXPY per vector */
+                for (int j = 0; j <= loc; ++j) {
+                    const double h = spo_dot(N, VV(loc + 1), VV(j));
+                    HH(j, loc) = h;
+                    spo_axpy(N, -h, VV(j), VV(loc + 1));
+                }
+            } else {
+                /* KSPGMRESClassicalGramSchmidtOrthogonalization: VecMDot, negate, VecMAXPY,
+                 * optional second pass (-ksp_gmres_cgs_refinement_type) */
+                int refine = opt->refine == 2;
+                for (int j = 0; j <= loc; ++j) lhh[j] = -spo_dot(N, VV(loc + 1), VV(j));
+                for (int j = 0; j <= loc; ++j) spo_axpy(N, lhh[j], VV(j), VV(loc + 1));
+                for (int j = 0; j <= loc; ++j) HH(j, loc) = -lhh[j];
+                if (opt->refine == 1) {
+                    double hnrm = 0.0;
+                    for (int j = 0; j <= loc; ++j) hnrm += lhh[j] * lhh[j];
+                    if (spo_vec_norm(N, VV(loc + 1)) < sqrt(hnrm)) refine = 1;
+                }
+                if (refine) {
+                    for (int j = 0; j <= loc; ++j) lhh[j] = -spo_dot(N, VV(loc + 1), VV(j));
+                    for (int j = 0; j <= loc; ++j) spo_axpy(N, lhh[j], VV(j), VV(loc + 1));
+                    for (int j = 0; j <= loc; ++j) HH(j, loc) -= lhh[j];
+                }
+            }
             tt = spo_vec_norm(N, VV(loc + 1));
             /* happy breakdown test */
             hapbnd = fabs(tt / rs[loc]);

@@ -151,7 +151,7 @@ void split_csr(int64_t row_begin, int32_t nrows_local, const int32_t *rowptr,
 // ---------------------------------------------------------------------------
 struct KrylovState {
     int32_t its, reason, done, loc_done;
-    int32_t max_it, restart, hapend, pad0;
+    int32_t max_it, restart, hapend, skip_refine;
     double rnorm, rnorm0, ttol, abstol, dtol, bnorm;
     double inv_tt;  // 1/||w|| of the last orthogonalised vector (or 1/||r||)
     double tt;
@@ -247,6 +247,12 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, const SchurP
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2,
                    const SchurPrep &prep, hipStream_t s);
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
+// CGS refinement: decide (device side) whether the second pass runs, then fold its results
+// (h2 into h, norm/traw of the refined vector over the first pass's)
+void krylov_refine_decide(const KrylovArrays &ka, int loc, int mode, const double *dots, const double *nrm2,
+                          double *dots2, hipStream_t s);
+void krylov_refine_merge(const KrylovArrays &ka, int loc, double *dots, const double *dots2, double *nrm,
+                         const double *nrm_b, int nn, hipStream_t s);
 }  // namespace k
 
 }  // namespace spk

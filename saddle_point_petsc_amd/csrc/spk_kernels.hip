@@ -499,7 +499,7 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t i2)
 // T threads per workgroup, G vectors loaded together (their 4*G 16-byte loads per
 // thread are all issued before the first FMA: the bytes in flight, not the
 // arithmetic, set the rate of this kernel).
-template <int NG, int T, int G, bool NT>
+template <int NG, int T, int G, bool NT, int U>
 __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, int64_t ldv, int nv,
                                                  const double *__restrict__ w, int64_t n2,
                                                  int64_t n_dot, double *__restrict__ partials,
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                                                  const int32_t *__restrict__ done)
 {
     if (done && *done) return;
-    constexpr int NA = NG * 8 + 1, W = T / kWave, TILE2 = T * kVecUnroll;
+    constexpr int NA = NG * 8 + 1, W = T / kWave, TILE2 = T * U;
     __shared__ double lds[(W * NA > T) ? W * NA : T];
     __shared__ int last;
     double acc[NA];
@@ -516,10 +516,10 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
     for (int i = 0; i < NA; ++i) acc[i] = 0.0;
 
     for (int64_t tile = blockIdx.x; tile * TILE2 < n2; tile += gridDim.x) {
-        double2 wv[kVecUnroll];
-        int64_t idx[kVecUnroll];
+        double2 wv[U];
+        int64_t idx[U];
 #pragma unroll
-        for (int u = 0; u < kVecUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
             idx[u] = tile * TILE2 + u * T + threadIdx.x;
             if (idx[u] < n2) {
                 wv[u] = ld2(w, idx[u]);
@@ -531,24 +531,24 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
             }
         }
 #pragma unroll
-        for (int u = 0; u < kVecUnroll; ++u) acc[NA - 1] += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
+        for (int u = 0; u < U; ++u) acc[NA - 1] += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
 #pragma unroll
         for (int g0 = 0; g0 < NG * 8; g0 += G) {
             if (g0 < nv) {  // wave-uniform
-                double2 a[G][kVecUnroll];
+                double2 a[G][U];
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
                     const int ic = (g0 + v < nv) ? g0 + v : nv - 1;  // clamp: re-reads a cached vector
                     const double *Vi = V + (size_t)ic * ldv;
 #pragma unroll
-                    for (int u = 0; u < kVecUnroll; ++u) a[v][u] = ld2s<NT>(Vi, idx[u]);
+                    for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, idx[u]);
                 }
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
                     const double mk = (g0 + v < nv) ? 1.0 : 0.0;
                     double d = 0.0;
 #pragma unroll
-                    for (int u = 0; u < kVecUnroll; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                    for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
                     acc[g0 + v] += mk * d;
                 }
             }
@@ -578,6 +578,24 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
     reset_counter(counter);
 }
 
+// Workgroup shape of the reducing vector kernels: big vectors get 512 threads x 4 double2
+// (few fat workgroups: cheap finish), small ones get thinner tiles so that ~256 workgroups
+// still exist (a 131 k-row slab on 32 workgroups left 7/8 of the chip idle: 20 us instead of 5).
+struct VecShape {
+    int T, U, grid;
+};
+static VecShape vec_shape(int64_t n2)
+{
+    VecShape v;
+    if (n2 >= (int64_t)kVecMaxBlocks * 2048) { v.T = 512; v.U = 4; }
+    else if (n2 >= (int64_t)kVecMaxBlocks * 1024) { v.T = 256; v.U = 4; }
+    else if (n2 >= (int64_t)kVecMaxBlocks * 512) { v.T = 256; v.U = 2; }
+    else { v.T = 256; v.U = 1; }
+    int64_t tiles = (n2 + (int64_t)v.T * v.U - 1) / ((int64_t)v.T * v.U);
+    if (tiles < 1) tiles = 1;
+    v.grid = (int)(tiles < kVecMaxBlocks ? tiles : kVecMaxBlocks);
+    return v;
+}
 static int vec_grid(int64_t n2, int T = kVT)
 {
     int64_t tiles = (n2 + (int64_t)T * kVecUnroll - 1) / ((int64_t)T * kVecUnroll);
@@ -586,15 +604,15 @@ static int vec_grid(int64_t n2, int T = kVT)
     return (int)(tiles < cap ? tiles : cap);
 }
 
-template <int T, int G, bool NT>
+template <int T, int U>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *w,
                         int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo, const int32_t *done)
 {
     switch (ng) {
-    case 1: hipLaunchKernelGGL((mdot_kernel<1, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-    case 2: hipLaunchKernelGGL((mdot_kernel<2, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-    case 3: hipLaunchKernelGGL((mdot_kernel<3, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-    default: hipLaunchKernelGGL((mdot_kernel<4, T, G, NT>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    case 1: hipLaunchKernelGGL((mdot_kernel<1, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    case 2: hipLaunchKernelGGL((mdot_kernel<2, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    case 3: hipLaunchKernelGGL((mdot_kernel<3, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    default: hipLaunchKernelGGL((mdot_kernel<4, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
     }
 }
 
@@ -602,10 +620,8 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
           const Finish &f, const int32_t *done, hipStream_t s)
 {
     if (nv > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: nv=%d exceeds %d", nv, kMaxNv - 1);
-    static const int variant = env_int("SPK_MDOT_VARIANT", 3);
-    const int T = (variant == 0) ? 1024 : (variant == 4 ? 256 : 512);
     const int64_t n2 = (n + 1) / 2;
-    const int grid = vec_grid(n2, T);
+    const VecShape vs = vec_shape(n2);
     // up to 32 vectors per launch; w.w is produced by the last launch
     int v0 = 0;
     do {
@@ -616,22 +632,10 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         double *oo = f.out + v0;
         unsigned *cn = f.counter;
         const int ng = cnt <= 8 ? 1 : cnt <= 16 ? 2 : cnt <= 24 ? 3 : 4;
-        static const int nt = env_int("SPK_NT", 1);
-        if (nt) {
-            switch (variant) {
-            case 2: mdot_launch<512, 8, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            case 4: mdot_launch<256, 8, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            case 0: mdot_launch<1024, 2, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            default: mdot_launch<512, 4, true>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            }
-        } else {
-            switch (variant) {
-            case 2: mdot_launch<512, 8, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            case 4: mdot_launch<256, 8, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            case 0: mdot_launch<1024, 2, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            default: mdot_launch<512, 4, false>(ng, grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-            }
-        }
+        if (vs.T == 512) mdot_launch<512, 4>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
+        else if (vs.U == 4) mdot_launch<256, 4>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
+        else if (vs.U == 2) mdot_launch<256, 2>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
+        else mdot_launch<256, 1>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
         v0 += 32;
     } while (v0 < nv);
 }
@@ -641,7 +645,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
 // the squared norm of the updated w (first n_dot entries) is produced in the
 // same pass -> VecNorm costs no extra sweep.
 // ---------------------------------------------------------------------------
-template <int T, int G, bool NT, int MP>
+template <int T, int G, bool NT, int MP, int U>
 __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, int64_t ldv,
                                                          int nv, const int32_t *__restrict__ nv_dev,
                                                          const double *__restrict__ a, double sign,
@@ -662,20 +666,20 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
     double tacc[MP > 0 ? MP : 1];
 #pragma unroll
     for (int r = 0; r < (MP > 0 ? MP : 1); ++r) tacc[r] = 0.0;
-    for (int64_t tile = blockIdx.x; tile * (T * kVecUnroll) < n2; tile += gridDim.x) {
-        double2 wv[kVecUnroll];
-        int64_t idx[kVecUnroll];
-        bool ok[kVecUnroll];
+    for (int64_t tile = blockIdx.x; tile * (T * U) < n2; tile += gridDim.x) {
+        double2 wv[U];
+        int64_t idx[U];
+        bool ok[U];
 #pragma unroll
-        for (int u = 0; u < kVecUnroll; ++u) {
-            idx[u] = tile * (T * kVecUnroll) + u * T + threadIdx.x;
+        for (int u = 0; u < U; ++u) {
+            idx[u] = tile * (T * U) + u * T + threadIdx.x;
             ok[u] = idx[u] < n2;
             if (!ok[u]) idx[u] = 0;
             wv[u] = ld2(w, idx[u]);
         }
         // G vectors per group: their 4*G loads are all in flight before the first FMA
         for (int g0 = 0; g0 < nv; g0 += G) {
-            double2 t[G][kVecUnroll];
+            double2 t[G][U];
             double ai[G];
 #pragma unroll
             for (int v = 0; v < G; ++v) {
@@ -683,19 +687,19 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                 ai[v] = (g0 + v < nv) ? sign * a[ic] : 0.0;
                 const double *Vi = V + (size_t)ic * ldv;
 #pragma unroll
-                for (int u = 0; u < kVecUnroll; ++u) t[v][u] = ld2s<NT>(Vi, idx[u]);
+                for (int u = 0; u < U; ++u) t[v][u] = ld2s<NT>(Vi, idx[u]);
             }
 #pragma unroll
             for (int v = 0; v < G; ++v) {
 #pragma unroll
-                for (int u = 0; u < kVecUnroll; ++u) {
+                for (int u = 0; u < U; ++u) {
                     wv[u].x += ai[v] * t[v][u].x;
                     wv[u].y += ai[v] * t[v][u].y;
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < kVecUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (ok[u]) {
                 reinterpret_cast<double2 *>(w)[idx[u]] = wv[u];
                 if (2 * idx[u] < n_dot) nrm += wv[u].x * wv[u].x;
@@ -708,11 +712,11 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
 #pragma unroll
             for (int r = 0; r < MP; ++r) {
                 if (r < m) {
-                    double2 e[kVecUnroll];
+                    double2 e[U];
 #pragma unroll
-                    for (int u = 0; u < kVecUnroll; ++u) e[u] = ld2s<NT>(bd + (size_t)r * ldb, idx[u]);
+                    for (int u = 0; u < U; ++u) e[u] = ld2s<NT>(bd + (size_t)r * ldb, idx[u]);
 #pragma unroll
-                    for (int u = 0; u < kVecUnroll; ++u) {
+                    for (int u = 0; u < U; ++u) {
                         if (ok[u]) {
                             if (2 * idx[u] < n_bd) tacc[r] += e[u].x * wv[u].x;
                             if (2 * idx[u] + 1 < n_bd) tacc[r] += e[u].y * wv[u].y;
@@ -747,20 +751,30 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
     reset_counter(counter);
 }
 
+template <int T, int U>
+static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64_t ldv, int nv, const int32_t *nv_dev,
+                         const double *a, double sign, double *w, int64_t n2, int64_t n_dot, const Finish &f,
+                         const double *bd, int64_t ldb, int64_t n_bd, int m, const int32_t *done)
+{
+#define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, 4, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
+                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, done)
+    if (mp == 4) SPK_MAXPY(4);
+    else if (mp == 8) SPK_MAXPY(8);
+    else SPK_MAXPY(0);
+#undef SPK_MAXPY
+}
+
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
            const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m)
 {
     const int64_t n2 = (n + 1) / 2;
-    constexpr int T = 512, G = 4;
-    const int grid = vec_grid(n2, T);
+    const VecShape vs = vec_shape(n2);
     const int mp = (bd && m > 0) ? (m <= 4 ? 4 : 8) : 0;
-#define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, G, true, MPP>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          coef_sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, done)
-    if (mp == 4) SPK_MAXPY(4);
-    else if (mp == 8) SPK_MAXPY(8);
-    else SPK_MAXPY(0);
-#undef SPK_MAXPY
+    if (vs.T == 512) maxpy_launch<512, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
+    else if (vs.U == 4) maxpy_launch<256, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
+    else if (vs.U == 2) maxpy_launch<256, 2>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
+    else maxpy_launch<256, 1>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1188,6 +1202,7 @@ __global__ void krylov_init_kernel(KrylovArrays ka, spk_opts o, const double *bn
     st->max_it = o.max_it;
     st->restart = o.restart;
     st->hapend = 0;
+    st->skip_refine = 1;
     st->bnorm = sqrt(*bnorm2);
     st->abstol = o.abstol;
     st->dtol = o.dtol;
@@ -1318,28 +1333,73 @@ void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const do
     hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2, prep);
 }
 
-// back substitution for the loc_done columns built in this cycle
-__global__ void krylov_cycle_end_kernel(KrylovArrays ka)
+// -ksp_gmres_cgs_refinement_type: mode 2 (always) refines unless done; mode 1 (ifneeded)
+// refines when ||w'|| < ||h|| (PETSc's test); the second-pass kernels take skip_refine as
+// their "done" word.  dots2 is zeroed so that a skipped pass merges as a no-op.
+__global__ void krylov_refine_decide_kernel(KrylovArrays ka, int loc, int mode, const double *dots,
+                                            const double *nrm2, double *dots2)
 {
+    KrylovState *st = ka.st;
+    if ((int)threadIdx.x <= loc) dots2[threadIdx.x] = 0.0;
     if (threadIdx.x != 0) return;
+    int skip = st->done ? 1 : 0;
+    if (!skip && mode == SPK_REFINE_IFNEEDED) {
+        double hn = 0.0;
+        for (int j = 0; j <= loc; ++j) hn += dots[j] * dots[j];
+        skip = !(sqrt(*nrm2) < sqrt(hn));
+    }
+    st->skip_refine = skip;
+}
+void krylov_refine_decide(const KrylovArrays &ka, int loc, int mode, const double *dots, const double *nrm2,
+                          double *dots2, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_refine_decide_kernel, dim3(1), dim3(64), 0, s, ka, loc, mode, dots, nrm2, dots2);
+}
+__global__ void krylov_refine_merge_kernel(KrylovArrays ka, int loc, double *dots, const double *dots2,
+                                           double *nrm, const double *nrm_b, int nn)
+{
+    if (ka.st->skip_refine) return;
+    if ((int)threadIdx.x <= loc) dots[threadIdx.x] += dots2[threadIdx.x];
+    if ((int)threadIdx.x < nn) nrm[threadIdx.x] = nrm_b[threadIdx.x];
+}
+void krylov_refine_merge(const KrylovArrays &ka, int loc, double *dots, const double *dots2, double *nrm,
+                         const double *nrm_b, int nn, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_refine_merge_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, dots2, nrm, nrm_b, nn);
+}
+
+// back substitution for the loc_done columns built in this cycle; the triangle is staged
+// in LDS by the whole workgroup first (450 dependent global loads took 47 us)
+__global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka)
+{
+    __shared__ double Hs[(kMaxNv) * (kMaxNv + 1)];
+    __shared__ double rss[kMaxNv + 2], ys[kMaxNv + 2];
     KrylovState *st = ka.st;
     const int n = st->loc_done, ldh = ka.ldh;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int k = e % n, j = e / n;  // row k, column j
+        Hs[j * n + k] = ka.H[(size_t)ldh * j + k];
+    }
+    for (int k = threadIdx.x; k < n; k += blockDim.x) rss[k] = ka.rs[k];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     for (int k = n - 1; k >= 0; --k) {
-        double t = ka.rs[k];
-        for (int j = k + 1; j < n; ++j) t -= ka.H[(size_t)ldh * j + k] * ka.nrs[j];
-        const double piv = ka.H[(size_t)ldh * k + k];
+        double t = rss[k];
+        for (int j = k + 1; j < n; ++j) t -= Hs[j * n + k] * ys[j];
+        const double piv = Hs[k * n + k];
         if (piv == 0.0) {
             if (st->reason >= 0) st->reason = SPK_DIVERGED_BREAKDOWN;
             st->done = 1;
             st->loc_done = 0;
             return;
         }
-        ka.nrs[k] = t / piv;
+        ys[k] = t / piv;
     }
+    for (int k = 0; k < n; ++k) ka.nrs[k] = ys[k];
 }
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s)
 {
-    hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(64), 0, s, ka);
+    hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka);
 }
 
 }  // namespace k

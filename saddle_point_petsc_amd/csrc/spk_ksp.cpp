@@ -163,10 +163,14 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
         } else if (key == "-ksp_gmres_classicalgramschmidt") {
             k->opts.orthog = SPK_ORTHOG_CGS;
         } else if (key == "-ksp_gmres_modifiedgramschmidt") {
-            return bad();
+            k->opts.orthog = SPK_ORTHOG_MGS;
         } else if (key == "-ksp_gmres_cgs_refinement_type") {
             if (!val) return need("a type");
-            if (std::string(val) != "never" && std::string(val) != "refine_never") return bad();
+            const std::string v(val);
+            if (v == "never" || v == "refine_never") k->opts.cgs_refine = SPK_REFINE_NEVER;
+            else if (v == "ifneeded" || v == "refine_ifneeded") k->opts.cgs_refine = SPK_REFINE_IFNEEDED;
+            else if (v == "always" || v == "refine_always") k->opts.cgs_refine = SPK_REFINE_ALWAYS;
+            else return bad();
         } else if (key == "-ksp_pc_side") {
             if (!val) return need("a side");
             if (std::string(val) != "right") return bad();

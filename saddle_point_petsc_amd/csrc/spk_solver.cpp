@@ -410,7 +410,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
 {
     if (!c->have_A) fail(SPK_ERR_STATE, "fgmres: no operator");
     if (!c->pc_ready) fail(SPK_ERR_STATE, "fgmres: call spk_pc_setup first (KSPSetUp)");
-    if (o.orthog != SPK_ORTHOG_CGS) fail(SPK_ERR_UNSUPPORTED, "fgmres: only classical Gram-Schmidt is implemented");
+    if (o.orthog != SPK_ORTHOG_CGS && o.orthog != SPK_ORTHOG_MGS) fail(SPK_ERR_ARG, "fgmres: unknown orthogonalisation %d", o.orthog);
+    if (o.cgs_refine < SPK_REFINE_NEVER || o.cgs_refine > SPK_REFINE_ALWAYS) fail(SPK_ERR_ARG, "fgmres: unknown cgs_refine %d", o.cgs_refine);
     ensure_krylov(c, o);
     hipStream_t s = c->stream;
     const int mk = o.restart;
@@ -489,12 +490,36 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
             }
-            // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 in the same pass)
-            k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm), done, s);
-            c->comm->allreduce_sum(sm, loc + 2, s);
-            if (fused) k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s, c->bd.p, ld, nl, m);
-            else k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s);
-            c->comm->allreduce_sum(sm + 64, fused ? 1 + m : 1, s);
+            const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY
+            const double *bdp = fused ? c->bd.p : nullptr;
+            if (o.orthog == SPK_ORTHOG_MGS) {
+                // KSPGMRESModifiedGramSchmidtOrthogonalization: one dot + one axpy per basis vector
+                for (int j = 0; j <= loc; ++j) {
+                    k::mdot(Vj(j), ld, 1, w, N, n_dot, c->fin(sm + j), done, s);
+                    c->comm->allreduce_sum(sm + j, 1, s);
+                    const bool lastv = j == loc;
+                    k::maxpy(Vj(j), ld, 1, nullptr, sm + j, -1.0, w, N, n_dot, c->fin(lastv ? sm + 64 : nullptr), done, s,
+                             lastv ? bdp : nullptr, ld, nl, m);
+                }
+                c->comm->allreduce_sum(sm + 64, nn, s);
+            } else {
+                // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 in the same pass)
+                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm), done, s);
+                c->comm->allreduce_sum(sm, loc + 2, s);
+                k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s, bdp, ld, nl, m);
+                c->comm->allreduce_sum(sm + 64, nn, s);
+                if (o.cgs_refine != SPK_REFINE_NEVER) {
+                    // second pass on the device's own decision (-ksp_gmres_cgs_refinement_type)
+                    const int32_t *skip = &c->kst.p->skip_refine;
+                    double *sm2 = sm + 192, *nb = sm + 320;
+                    k::krylov_refine_decide(c->ka, loc, o.cgs_refine, sm, sm + 64, sm2, s);
+                    k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm2), skip, s);
+                    c->comm->allreduce_sum(sm2, loc + 2, s);
+                    k::maxpy(V, ld, loc + 1, nullptr, sm2, -1.0, w, N, n_dot, c->fin(nb), skip, s, bdp, ld, nl, m);
+                    c->comm->allreduce_sum(nb, nn, s);
+                    k::krylov_refine_merge(c->ka, loc, sm, sm2, sm + 64, nb, nn, s);
+                }
+            }
             // Hessenberg column, Givens, convergence (+ the next apply's m-vector data) -- on the device
             k::krylov_givens(c->ka, loc, sm, sm + 64, prep_for(w), s);
             if (!fused) k::scale_dev(w, N, inv_tt, done, s);  // v_{j+1} = w / ||w||

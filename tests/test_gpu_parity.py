@@ -192,6 +192,24 @@ def test_fused_schur_path_equals_unfused(spk, oracle, fact, mx, my):
     assert relerr(xf, xu) < 1e-8 and relerr(xf, xo) < 1e-8
 
 
+@pytest.mark.parametrize("kw", [dict(orthog=1), dict(cgs_refine=2), dict(cgs_refine=1)])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_orthogonalisation_options(spk, oracle, kw, fused):
+    """-ksp_gmres_modifiedgramschmidt and -ksp_gmres_cgs_refinement_type {ifneeded,always}."""
+    A, f = spk.AssembleOperator_Laplace(32)
+    B, g = spk.AssembleOperator_Constraints(32)
+    rhs = np.concatenate([f, g])
+    okw = dict(orthog=kw.get("orthog", 0), refine=kw.get("cgs_refine", 0))
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x, info = c.fgmres(rhs, rtol=1e-10, fused=fused, **kw)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10, **okw)
+    _check_iteration_parity(info, io)
+    assert relerr(x, xo) < 1e-8
+
+
 def test_fgmres_rtol_1e8_iteration_counts(spk, golden_m32):
     A, f = spk.AssembleOperator_Laplace(32)
     B, g = spk.AssembleOperator_Constraints(32)

@@ -178,7 +178,11 @@ def test_ksp_options_follow_the_petsc_names(spk):
     o, pc, sf = k.getOptions()
     assert (o.rtol, o.abstol, o.dtol, o.max_it, o.restart, o.guess_nonzero) == (1e-8, 1e-30, 1e6, 250, 20, 1)
     assert pc == spk.PC_SCHUR and sf == spk.SCHUR_LOWER
-    for bad in ("-ksp_type cg", "-pc_type ilu", "-ksp_rtol", "-ksp_rtol abc", "-ksp_gmres_modifiedgramschmidt",
+    k.setFromOptions("-ksp_gmres_modifiedgramschmidt -ksp_gmres_cgs_refinement_type ifneeded")
+    assert (k.getOptions()[0].orthog, k.getOptions()[0].cgs_refine) == (1, 1)
+    k.setFromOptions("-ksp_gmres_classicalgramschmidt -ksp_gmres_cgs_refinement_type never")
+    assert (k.getOptions()[0].orthog, k.getOptions()[0].cgs_refine) == (0, 0)
+    for bad in ("-ksp_type cg", "-pc_type ilu", "-ksp_rtol", "-ksp_rtol abc", "-ksp_gmres_cgs_refinement_type twice",
                 "-ksp_bogus 3", "-pc_fieldsplit_schur_fact_type half", "-fieldsplit_0_pc_type lu"):
         with pytest.raises(spk.SpkError):
             k.setFromOptions(bad)
