@@ -42,6 +42,14 @@ int SpkAssembleOperator_Constraints(int mx, int my, int64_t row_begin, int64_t r
                                     int32_t *colidx, double *val);
 int SpkAssembleRHS_Constraints(double *g4);
 
+/* Legacy-VTK ASCII output of the solution on the node grid: what WriteVTK(da_u, u,
+ * "test.vtk") at /root/reference/src/SaddlePointProblem.c:22 is meant to produce.  The
+ * reference's writer (Visulaization.c:3-67) emits points and polygons only and never the
+ * field (its local vector is obtained at :27-28 and never filled); this one writes a
+ * STRUCTURED_GRID with the node coordinates and POINT_DATA VECTORS U = (Ux, Uy, 0).
+ * u has 2*mx*my entries in the natural ordering (j*mx + i)*2 + c. */
+int SpkWriteVTK(int mx, int my, const double *u, const char *filename);
+
 /* Element kernels (exposed for the known-answer tests): 8x8 stress-form
  * stiffness Ke[a*8+b] (Discretization.c:293-332) and load Fe (:334-374) for an
  * element with corner coordinates xe[8] = {x0,y0,x1,y1,x2,y2,x3,y3} in the

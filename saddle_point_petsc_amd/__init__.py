@@ -8,7 +8,7 @@ from ._lib import lib, SpkError, LIB_PATH  # noqa: F401
 from .csr import CSR  # noqa: F401
 from .assembly import (  # noqa: F401
     AssembleOperator_Laplace, AssembleOperator_Constraints, FormStressOperatorQ12D,
-    FormLaplaceRHSQ12D, grid_sizes, partition_slab,
+    FormLaplaceRHSQ12D, grid_sizes, partition_slab, WriteVTK,
 )
 from .solver import (  # noqa: F401
     Context, KSP, LocalGroup, default_opts, unique_id,

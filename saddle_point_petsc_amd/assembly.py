@@ -74,6 +74,15 @@ def FormLaplaceRHSQ12D(xe):
     return Fe
 
 
+def WriteVTK(mx, my, u, filename):
+    """Legacy-VTK file with the node grid and the solution field (the reference's
+    WriteVTK, SaddlePointProblem.c:22, never wrote the field)."""
+    u = np.ascontiguousarray(u, np.float64)
+    if u.shape != (2 * mx * my,):
+        raise ValueError("u must have 2*mx*my entries")
+    _chk(lib.SpkWriteVTK(mx, my, u, str(filename).encode()), "SpkWriteVTK")
+
+
 def partition_slab(mx, my, rank, nranks):
     """Rows of `rank` when the my node lines are dealt in contiguous slabs."""
     b, e = C.c_int64(), C.c_int64()

@@ -7,7 +7,7 @@
 //
 //   saddle_point_run -da_grid_x 257 -da_grid_y 257 -ksp_type fgmres -ksp_rtol 1e-8 \
 //       -pc_type fieldsplit -pc_fieldsplit_type schur -pc_fieldsplit_schur_fact_type full \
-//       -ksp_converged_reason [-saddle 0] [-solution_view]
+//       -ksp_converged_reason [-saddle 0] [-solution_view] [-no_vtk]
 //
 // The reference hard-codes Nx = Ny = 3 elements (main.c:14), i.e. a 4 x 4 node
 // grid; that is the default here too.  -saddle 0 solves A u = f alone, as the
@@ -88,6 +88,8 @@ int main(int argc, char **argv)
     if (opt_flag(argc, argv, "-solution_view")) {  // VecViewFromOptions(u, NULL, "-solution_view"), :20
         for (int64_t i = 0; i < n + (saddle ? 4 : 0); ++i) std::printf("%.15e\n", sol[(size_t)i]);
     }
+    // WriteVTK(da_u, u, "test.vtk"), SaddlePointProblem.c:22 -- with the field this time
+    if (!opt_flag(argc, argv, "-no_vtk")) CHK(SpkWriteVTK(mx, my, sol.data(), "test.vtk"));
     CHK(SpkKSPDestroy(&ksp));
     return reason > 0 ? 0 : 2;
 }

@@ -8,6 +8,7 @@
 // so every stored value is bit-identical to a sequential ADD_VALUES assembly
 // while no two threads ever touch the same entry.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -295,6 +296,21 @@ int SpkAssembleRHS_Constraints(double *g)
     if (!g) return SPK_ERR_ARG;
     g[0] = 1e-2; g[1] = -2e-2; g[2] = 3e-3; g[3] = 1e-3;
     return SPK_OK;
+}
+
+int SpkWriteVTK(int mx, int my, const double *u, const char *filename)
+{
+    if (mx < 2 || my < 2 || !u || !filename) return SPK_ERR_ARG;
+    FILE *fp = std::fopen(filename, "w");
+    if (!fp) return SPK_ERR_ARG;
+    std::fprintf(fp, "# vtk DataFile Version 3.0\nsaddle point solution U on a %d x %d node grid\nASCII\n", mx, my);
+    std::fprintf(fp, "DATASET STRUCTURED_GRID\nDIMENSIONS %d %d 1\nPOINTS %lld double\n", mx, my, (long long)mx * my);
+    for (int j = 0; j < my; ++j)
+        for (int i = 0; i < mx; ++i) std::fprintf(fp, "%.17g %.17g 0\n", coord(i, mx), coord(j, my));
+    std::fprintf(fp, "POINT_DATA %lld\nVECTORS U double\n", (long long)mx * my);
+    for (int64_t p = 0; p < (int64_t)mx * my; ++p) std::fprintf(fp, "%.17g %.17g 0\n", u[2 * p], u[2 * p + 1]);
+    const bool ok = std::ferror(fp) == 0;
+    return (std::fclose(fp) == 0 && ok) ? SPK_OK : SPK_ERR_ARG;
 }
 
 int SpkFormStressOperatorQ12D(const double *xe, const double *coeff4, double *Ke64)

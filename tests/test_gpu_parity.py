@@ -352,8 +352,11 @@ def test_driver_executable_reference_default_problem(spk, appendix_b, golden_m32
     reference's Nx = Ny = 3 elements; as written there the solve is A u = f."""
     import os, subprocess
     exe = os.path.join(os.path.dirname(spk.LIB_PATH), "saddle_point_run")
+    import tempfile
+    wd = tempfile.mkdtemp()
     out = subprocess.run([exe, "-saddle", "0", "-ksp_type", "fgmres", "-pc_type", "jacobi", "-ksp_rtol", "1e-12",
-                          "-solution_view"], capture_output=True, text=True, timeout=120)
+                          "-solution_view"], capture_output=True, text=True, timeout=120, cwd=wd)
+    assert "VECTORS U double" in open(os.path.join(wd, "test.vtk")).read()
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.strip().splitlines()
     assert "CONVERGED_RTOL" in lines[0] and "4 x 4 nodes, 32 rows" in lines[0]
@@ -362,12 +365,12 @@ def test_driver_executable_reference_default_problem(spk, appendix_b, golden_m32
         assert u[int(idx)] == pytest.approx(v, abs=2e-12)
     out = subprocess.run([exe, "-da_grid_x", "32", "-da_grid_y", "32", "-ksp_type", "fgmres", "-ksp_rtol", "1e-8",
                           "-pc_type", "fieldsplit", "-pc_fieldsplit_type", "schur",
-                          "-pc_fieldsplit_schur_fact_type", "full", "-ksp_converged_reason"],
-                         capture_output=True, text=True, timeout=120)
+                          "-pc_fieldsplit_schur_fact_type", "full", "-ksp_converged_reason", "-no_vtk"],
+                         capture_output=True, text=True, timeout=120, cwd=wd)
     assert out.returncode == 0, out.stdout + out.stderr
     its = int(out.stdout.split("after ")[1].split(" iterations")[0])
     assert abs(its - golden_m32["schur_its"][3]) <= 1
-    bad = subprocess.run([exe, "-ksp_type", "cg"], capture_output=True, text=True, timeout=120)
+    bad = subprocess.run([exe, "-ksp_type", "cg"], capture_output=True, text=True, timeout=120, cwd=wd)
     assert bad.returncode == 1 and "not supported" in bad.stderr
 
 

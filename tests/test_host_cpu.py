@@ -117,6 +117,21 @@ def test_assembler_rejects_bad_arguments(spk):
         spk.AssembleOperator_Constraints(2, 2)
 
 
+def test_vtk_writer_emits_the_field(spk, golden_m4, tmp_path):
+    """Unlike the reference's writer (Visulaization.c:27-28 never serialises u)."""
+    fn = tmp_path / "test.vtk"
+    spk.WriteVTK(4, 4, golden_m4["u"], fn)
+    lines = fn.read_text().splitlines()
+    assert lines[0].startswith("# vtk DataFile") and "DATASET STRUCTURED_GRID" in lines
+    i = lines.index("VECTORS U double")
+    vals = np.array([[float(t) for t in ln.split()] for ln in lines[i + 1:i + 17]])
+    assert np.array_equal(vals[:, :2].reshape(-1), golden_m4["u"]) and not vals[:, 2].any()
+    pts = np.array([[float(t) for t in ln.split()] for ln in lines[lines.index("POINTS 16 double") + 1:][:16]])
+    assert pts[5, 0] == pytest.approx(1 / 3) and pts[5, 1] == pytest.approx(1 / 3)
+    with pytest.raises(spk.SpkError):
+        spk.WriteVTK(4, 4, golden_m4["u"], tmp_path / "missing_dir" / "x.vtk")
+
+
 # --------------------------------------------------------------------------- partition
 def _split(spk, A):
     i64, i32 = C.c_int64, C.c_int32
