@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -40,18 +41,23 @@ struct spk_local_group {
     // host staging for allgather
     std::vector<std::vector<char>> stage;
 
+    // bounded: a rank that failed (exception) must not leave the others waiting forever
     void barrier()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (broken) spk::fail(SPK_ERR_COMM, "local group: a rank has failed");
         const long gen = generation;
         if (++arrived == nranks) {
             arrived = 0;
             ++generation;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen; });
+        } else if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; }) || broken) {
+            broken = true;
+            cv.notify_all();
+            spk::fail(SPK_ERR_COMM, "local group: barrier timed out or a rank failed");
         }
     }
+    bool broken = false;
 };
 
 namespace spk {

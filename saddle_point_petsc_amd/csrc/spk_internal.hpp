@@ -173,15 +173,6 @@ struct Finish {
     double *out;
 };
 
-// m-vector bookkeeping of the fused Schur path (all pointers: device memory)
-struct SchurPrep {
-    int m, fact;            // m = 0 disables
-    const double *w1;       // lambda part of the un-normalised new basis vector
-    const double *traw;     // B D w' (reduced)
-    const double *shat, *gram;
-    double *y1, *x1, *w1next;
-};
-
 // y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
           const int32_t *done, hipStream_t s, bool accumulate = false);
@@ -210,12 +201,11 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
 // with bd != nullptr also f.out[1+r] = sum_i bd[i*MP + r] * w_new[i], i < n_bd (fused Schur path)
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
-           const int32_t *done, hipStream_t s, const double *bd = nullptr, int64_t ldb = 0, int64_t n_bd = 0, int m = 0);
+           const int32_t *done, hipStream_t s, const double *bd = nullptr, int64_t ldb = 0, int64_t n_bd = 0, int m = 0,
+           double *w1side = nullptr);
 void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *bd, hipStream_t s);
 void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
-               const Finish &f, const int32_t *done, hipStream_t s);
-void fused_scale_pc(double *v, const double *inv_tt, const double *dinv, const double *bd, int64_t ldb,
-                    const SchurPrep &p, int64_t nl, double *z, double *c, const int32_t *done, hipStream_t s);
+               double *w1side, const Finish &f, const int32_t *done, hipStream_t s);
 // x *= *alpha_dev
 void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s);
 // y = a*x + b*y with host scalars (b = 0: y = a*x without reading y)
@@ -243,9 +233,13 @@ struct KrylovArrays {
     int32_t hist_cap, ldh;
 };
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, const SchurPrep &prep, hipStream_t s);
-void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2,
-                   const SchurPrep &prep, hipStream_t s);
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s);
+void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
+// head of a fused Schur iteration: VecScale + PCApply + B^T part of MatMult in one pass, plus the
+// previous iteration's Givens step in workgroup 0 (loc_prev < 0: none)
+void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
+                const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
+                const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s);
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          unsigned *__restrict__ counter,
                                                          double *__restrict__ out,
                                                          const double *__restrict__ bd, int64_t ldb,
-                                                         int64_t n_bd, int m,
+                                                         int64_t n_bd, int m, double *__restrict__ w1side,
                                                          const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -704,6 +704,11 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                 reinterpret_cast<double2 *>(w)[idx[u]] = wv[u];
                 if (2 * idx[u] < n_dot) nrm += wv[u].x * wv[u].x;
                 if (2 * idx[u] + 1 < n_dot) nrm += wv[u].y * wv[u].y;
+                if (MP > 0 && w1side) {  // lambda part of the un-normalised vector, for the next head kernel
+                    const int64_t e0 = 2 * idx[u] - n_bd;
+                    if (e0 >= 0 && e0 < m) w1side[e0] = wv[u].x;
+                    if (e0 + 1 >= 0 && e0 + 1 < m) w1side[e0 + 1] = wv[u].y;
+                }
             }
         }
         if (MP > 0) {
@@ -754,10 +759,10 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
 template <int T, int U>
 static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64_t ldv, int nv, const int32_t *nv_dev,
                          const double *a, double sign, double *w, int64_t n2, int64_t n_dot, const Finish &f,
-                         const double *bd, int64_t ldb, int64_t n_bd, int m, const int32_t *done)
+                         const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side, const int32_t *done)
 {
 #define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, 4, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, done)
+                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
     else SPK_MAXPY(0);
@@ -766,15 +771,15 @@ static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64
 
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
-           const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m)
+           const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side)
 {
     const int64_t n2 = (n + 1) / 2;
     const VecShape vs = vec_shape(n2);
     const int mp = (bd && m > 0) ? (m <= 4 ? 4 : 8) : 0;
-    if (vs.T == 512) maxpy_launch<512, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
-    else if (vs.U == 4) maxpy_launch<256, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
-    else if (vs.U == 2) maxpy_launch<256, 2>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
-    else maxpy_launch<256, 1>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, done);
+    if (vs.T == 512) maxpy_launch<512, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
+    else if (vs.U == 4) maxpy_launch<256, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
+    else if (vs.U == 2) maxpy_launch<256, 2>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
+    else maxpy_launch<256, 1>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1019,7 +1024,8 @@ void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *
 template <int MP>
 __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict__ x, int64_t n2, int64_t n_dot,
                                                         const double *__restrict__ bd, int64_t ldb, int64_t n_bd,
-                                                        int m, double *__restrict__ partials,
+                                                        int m, double *__restrict__ w1side,
+                                                        double *__restrict__ partials,
                                                         unsigned *__restrict__ counter, double *__restrict__ out,
                                                         const int32_t *__restrict__ done)
 {
@@ -1034,6 +1040,11 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
         const double2 v = reinterpret_cast<const double2 *>(x)[i];
         if (2 * i < n_dot) acc[0] += v.x * v.x;
         if (2 * i + 1 < n_dot) acc[0] += v.y * v.y;
+        {
+            const int64_t e0 = 2 * i - n_bd;
+            if (e0 >= 0 && e0 < m) w1side[e0] = v.x;
+            if (e0 + 1 >= 0 && e0 + 1 < m) w1side[e0 + 1] = v.y;
+        }
 #pragma unroll
         for (int r = 0; r < MP; ++r) {
             if (r < m) {
@@ -1062,78 +1073,14 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
     reset_counter(counter);
 }
 void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
-               const Finish &f, const int32_t *done, hipStream_t s)
+               double *w1side, const Finish &f, const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n + 1) / 2;
     const int grid = vec_grid(n2, 512);
     if (m <= 4)
-        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, f.partials, f.counter, f.out, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.counter, f.out, done);
     else
-        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, f.partials, f.counter, f.out, done);
-}
-
-// Fused "normalise + Schur preconditioner + B^T part of the operator" (one pass):
-//   v  = w' * inv_tt                          (VecScale of the new basis vector, in place)
-//   z0 = D v - (B D)^T y1   (FULL)  |  D v    (LOWER)       -> Z_j
-//   c  = B^T y1 = ((B D)^T y1) ./ dinv                      -> pre-load of the SpMV output
-// lambda parts (m values) are written by the first workgroup.
-template <int MP>
-__global__ __launch_bounds__(kThreads) void fused_scale_pc_kernel(
-    double *__restrict__ v, const double *__restrict__ inv_tt_p, const double *__restrict__ dinv,
-    const double *__restrict__ bd, int64_t ldb, const double *__restrict__ y1, const double *__restrict__ x1,
-    const double *__restrict__ w1next, int fact, int64_t nl, int m, double *__restrict__ z,
-    double *__restrict__ c, const int32_t *__restrict__ done)
-{
-    if (done && *done) return;
-    const double inv_tt = *inv_tt_p;
-    double yv[MP];
-#pragma unroll
-    for (int r = 0; r < MP; ++r) yv[r] = r < m ? y1[r] : 0.0;
-    const int64_t n2 = nl / 2;  // nl is even on this path (checked by the host)
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
-        double2 w = reinterpret_cast<double2 *>(v)[i];
-        const double2 d = reinterpret_cast<const double2 *>(dinv)[i];
-        w.x *= inv_tt;
-        w.y *= inv_tt;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < MP; ++r) {
-            if (r < m) {
-                const double2 e = ld2s<true>(bd + (size_t)r * ldb, i);
-                s0 += e.x * yv[r];
-                s1 += e.y * yv[r];
-            }
-        }
-        double2 zz, cc;
-        zz.x = w.x * d.x;
-        zz.y = w.y * d.y;
-        if (fact == SPK_SCHUR_FULL) {
-            zz.x -= s0;
-            zz.y -= s1;
-        }
-        cc.x = s0 / d.x;
-        cc.y = s1 / d.y;
-        reinterpret_cast<double2 *>(v)[i] = w;
-        reinterpret_cast<double2 *>(z)[i] = zz;
-        reinterpret_cast<double2 *>(c)[i] = cc;
-    }
-    if (blockIdx.x == 0 && (int)threadIdx.x < m) {
-        v[nl + threadIdx.x] = x1[threadIdx.x];
-        z[nl + threadIdx.x] = y1[threadIdx.x];
-        c[nl + threadIdx.x] = w1next[threadIdx.x];
-    }
-}
-void fused_scale_pc(double *v, const double *inv_tt, const double *dinv, const double *bd, int64_t ldb,
-                    const SchurPrep &p, int64_t nl, double *z, double *c, const int32_t *done, hipStream_t s)
-{
-    const int64_t n2 = nl / 2;
-    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
-    if (p.m <= 4)
-        hipLaunchKernelGGL(fused_scale_pc_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, inv_tt, dinv, bd, ldb,
-                           p.y1, p.x1, p.w1next, p.fact, nl, p.m, z, c, done);
-    else
-        hipLaunchKernelGGL(fused_scale_pc_kernel<8>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, inv_tt, dinv, bd, ldb,
-                           p.y1, p.x1, p.w1next, p.fact, nl, p.m, z, c, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.counter, f.out, done);
 }
 
 __global__ void sum_slots_kernel(const double *__restrict__ slots, int nslots, int ld, int count,
@@ -1164,33 +1111,6 @@ __device__ __forceinline__ int converged_default(double rnorm, const KrylovState
     return 0;
 }
 
-// Fused Schur path: right after the norm of the new basis vector is known, one
-// thread prepares the m-vector data of the NEXT preconditioner/operator apply:
-//   x1 = lambda part of v = w'/||w'||,   t = B D v = traw/||w'||,
-//   y1 = -(x1 - t)/S^                    (LOWER / FULL, S~ = -S^)
-//   w1 = B z0 = t - G y1 (FULL) | t (LOWER)   with G = B D B^T (m x m)
-// Called by the whole (single-wave) workgroup; lane r < m owns constraint r.
-__device__ __forceinline__ void schur_prepare(const SchurPrep &p, double inv_tt, double *y1_lds)
-{
-    const int r = threadIdx.x;
-    double t = 0.0;
-    if (r < p.m) {
-        const double x1 = p.w1[r] * inv_tt;
-        t = p.traw[r] * inv_tt;
-        const double y = -(x1 - t) / p.shat[r];
-        p.x1[r] = x1;
-        p.y1[r] = y;
-        y1_lds[r] = y;
-    }
-    __syncthreads();
-    if (r < p.m) {
-        double w = t;
-        if (p.fact == SPK_SCHUR_FULL)
-            for (int q = 0; q < p.m; ++q) w -= p.gram[r * p.m + q] * y1_lds[q];
-        p.w1next[r] = w;
-    }
-}
-
 __global__ void krylov_init_kernel(KrylovArrays ka, spk_opts o, const double *bnorm2)
 {
     if (threadIdx.x != 0) return;
@@ -1217,51 +1137,44 @@ void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2
     hipLaunchKernelGGL(krylov_init_kernel, dim3(1), dim3(64), 0, s, ka, o, bnorm2);
 }
 
-__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, SchurPrep prep)
+__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2)
 {
-    __shared__ double bc[2];
-    __shared__ double y1s[16];
+    if (threadIdx.x != 0) return;
     KrylovState *st = ka.st;
-    if (threadIdx.x == 0) {
-        bc[0] = 0.0;  // 1.0 -> run the Schur preparation
-        st->loc_done = 0;
-        if (!st->done) {
-            const double rnorm = sqrt(*nrm2);
-            st->rnorm = rnorm;
-            if (st->its == 0) {
-                st->rnorm0 = rnorm;
-                if (ka.hist_cap > 0) ka.hist[0] = rnorm;
-            }
-            int reason = converged_default(rnorm, st);
-            if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
-            st->reason = reason;
-            st->hapend = 0;
-            if (reason) {
-                st->done = 1;
-            } else {
-                ka.rs[0] = rnorm;
-                st->inv_tt = 1.0 / rnorm;
-                bc[0] = 1.0;
-                bc[1] = 1.0 / rnorm;
-            }
-        }
+    st->loc_done = 0;
+    if (st->done) return;
+    const double rnorm = sqrt(*nrm2);
+    st->rnorm = rnorm;
+    if (st->its == 0) {
+        st->rnorm0 = rnorm;
+        if (ka.hist_cap > 0) ka.hist[0] = rnorm;
     }
-    __syncthreads();
-    if (prep.m > 0 && bc[0] != 0.0) schur_prepare(prep, bc[1], y1s);
+    int reason = converged_default(rnorm, st);
+    if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
+    st->reason = reason;
+    st->hapend = 0;
+    if (reason) {
+        st->done = 1;
+        return;
+    }
+    ka.rs[0] = rnorm;
+    st->inv_tt = 1.0 / rnorm;
 }
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, const SchurPrep &prep, hipStream_t s)
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s)
 {
-    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, prep);
+    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2);
 }
 
-__global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2,
-                                     SchurPrep prep)
+// One Arnoldi step's scalar work (KSPFGMRESUpdateHessenberg + KSPConvergedDefault), run by a
+// whole workgroup: the lanes stage the column and the stored rotations in LDS (parallel
+// loads), lane 0 runs the dependent chain out of LDS and writes the column back once.
+// Called from the stand-alone kernel (generic path) and from workgroup 0 of the fused
+// iteration-head kernel, where it overlaps with that kernel's streaming.
+__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2)
 {
-    KrylovState *st = ka.st;
-    if (st->done) return;
-    // one wave stages the column and the stored rotations in LDS (parallel loads),
-    // lane 0 then runs the dependent chain out of LDS and writes the column back once
     __shared__ double Hc[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2];
+    KrylovState *st = ka.st;
+    if (st->done) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
     double *Hg = ka.H + (size_t)ldh * loc;  // column loc
     for (int j = threadIdx.x; j <= loc; j += blockDim.x) {
@@ -1269,11 +1182,8 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
         ccs[j] = ka.cc[j];
         sss[j] = ka.ss[j];
     }
-    __shared__ double bc[2];
-    __shared__ double y1s[16];
     __syncthreads();
-    if (threadIdx.x == 0) bc[0] = 0.0;
-    if (threadIdx.x == 0) [&]() {
+    if (threadIdx.x != 0) return;
     const double tt = sqrt(*nrm2);
     // happy breakdown test
     double hapbnd = fabs(tt / ka.rs[loc]);
@@ -1319,18 +1229,111 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
     if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
     st->reason = reason;
     if (reason) st->done = 1;
-    else {
-        bc[0] = 1.0;
-        bc[1] = st->inv_tt;
-    }
-    }();
-    __syncthreads();
-    if (prep.m > 0 && bc[0] != 0.0) schur_prepare(prep, bc[1], y1s);
 }
-void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2,
-                   const SchurPrep &prep, hipStream_t s)
+
+__global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
 {
-    hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2, prep);
+    givens_block(ka, loc, dots, nrm2);
+}
+void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s)
+{
+    hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2);
+}
+
+// Head of a fused Schur iteration (one pass over the new basis vector):
+//   v  = w' / ||w'||                          VecScale, in place
+//   z0 = D v - (B D)^T y1  (FULL) | D v (LOWER), z1 = y1        -> Z_j    (PCApply_FieldSplit_Schur)
+//   c  = B^T y1 = ((B D)^T y1) ./ dinv  -> pre-load of the SpMV output;  c1 = B z0 = t - G y1
+// Every workgroup derives the m-vector data itself from the reduced scalars of the previous
+// MAXPY pass (nrm[0] = ||w'||^2, nrm[1..m] = B D w'; w1raw = lambda part of w'):
+//   x1 = w1raw/||w'||, t = B D v, y1 = -(x1 - t)/S^.
+// Workgroup 0 additionally runs the Givens step of the PREVIOUS iteration (loc_prev >= 0),
+// which therefore costs no launch and overlaps with the streaming of the other workgroups.
+// Its `done` word may thus rise while this iteration's kernels are in flight: they then
+// only write vectors nobody reads again, the iterate is frozen by loc_done.
+template <int MP>
+__global__ __launch_bounds__(kThreads) void fused_head_kernel(
+    double *__restrict__ v, const double *__restrict__ nrm, const double *__restrict__ w1raw,
+    const double *__restrict__ dinv, const double *__restrict__ bd, int64_t ldb,
+    const double *__restrict__ shat, const double *__restrict__ gram, int fact, int64_t nl, int m,
+    double *__restrict__ z, double *__restrict__ c, KrylovArrays ka, int loc_prev,
+    const double *__restrict__ dots_prev, const int32_t *__restrict__ done)
+{
+    if (*done) return;
+    __shared__ double ys[MP], xs[MP], ts[MP];
+    const double tt = sqrt(nrm[0]);
+    const double inv_tt = tt > 1e-300 ? 1.0 / tt : 1.0;
+    if ((int)threadIdx.x < MP) {
+        const int r = threadIdx.x;
+        double x1 = 0.0, t = 0.0, y = 0.0;
+        if (r < m) {
+            x1 = w1raw[r] * inv_tt;
+            t = nrm[1 + r] * inv_tt;
+            y = -(x1 - t) / shat[r];
+        }
+        xs[r] = x1;
+        ts[r] = t;
+        ys[r] = y;
+    }
+    __syncthreads();
+    double yv[MP];
+#pragma unroll
+    for (int r = 0; r < MP; ++r) yv[r] = ys[r];
+
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < m) {
+            const int r = threadIdx.x;
+            double w1 = ts[r];
+            if (fact == SPK_SCHUR_FULL)
+                for (int q = 0; q < m; ++q) w1 -= gram[r * m + q] * ys[q];
+            v[nl + r] = xs[r];
+            z[nl + r] = ys[r];
+            c[nl + r] = w1;
+        }
+        if (loc_prev >= 0) givens_block(ka, loc_prev, dots_prev, nrm);
+    }
+
+    const int64_t n2 = nl / 2;  // nl is even on this path (checked by the host)
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+        double2 w = reinterpret_cast<double2 *>(v)[i];
+        const double2 d = reinterpret_cast<const double2 *>(dinv)[i];
+        w.x *= inv_tt;
+        w.y *= inv_tt;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < MP; ++r) {
+            if (r < m) {
+                const double2 e = ld2s<true>(bd + (size_t)r * ldb, i);
+                s0 += e.x * yv[r];
+                s1 += e.y * yv[r];
+            }
+        }
+        double2 zz, cc;
+        zz.x = w.x * d.x;
+        zz.y = w.y * d.y;
+        if (fact == SPK_SCHUR_FULL) {
+            zz.x -= s0;
+            zz.y -= s1;
+        }
+        cc.x = s0 / d.x;
+        cc.y = s1 / d.y;
+        reinterpret_cast<double2 *>(v)[i] = w;
+        reinterpret_cast<double2 *>(z)[i] = zz;
+        reinterpret_cast<double2 *>(c)[i] = cc;
+    }
+}
+void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
+                const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
+                const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = nl / 2;
+    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
+    if (m <= 4)
+        hipLaunchKernelGGL(fused_head_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, done);
+    else
+        hipLaunchKernelGGL(fused_head_kernel<8>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, done);
 }
 
 // -ksp_gmres_cgs_refinement_type: mode 2 (always) refines unless done; mode 1 (ifneeded)

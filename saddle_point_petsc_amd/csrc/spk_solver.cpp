@@ -428,10 +428,16 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     SPK_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();
 
+    // small[]: two parity sets so that a deferred Givens step (fused path) can still read iteration
+    // j-1's scalars while iteration j produces its own: dots at p*128, norm (+ B D w') at p*128+64
+    auto dotsbuf = [&](int p) { return sm + (p & 1) * 128; };
+    auto nrmbuf = [&](int p) { return sm + (p & 1) * 128 + 64; };
+    double *sm2 = sm + 256, *nrm2b = sm + 320, *bn2 = sm + 384, *w1side = c->y1tmp.p + 48;
+
     // ||b|| for KSPConvergedDefault
-    k::sqnorm(b, n_dot, c->fin(sm + 128), nullptr, s);
-    c->comm->allreduce_sum(sm + 128, 1, s);
-    k::krylov_init(c->ka, o, sm + 128, s);
+    k::sqnorm(b, n_dot, c->fin(bn2), nullptr, s);
+    c->comm->allreduce_sum(bn2, 1, s);
+    k::krylov_init(c->ka, o, bn2, s);
 
     // initial residual into V0
     if (!o.guess_nonzero) {
@@ -443,42 +449,36 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, nullptr, s);
     }
 
-    // fused Schur path: PC + B^T part of the operator + VecScale in one pass, B D w' in the maxpy pass
+    // fused Schur path: VecScale + PC + B^T part of the operator in one pass ("head"), B D w' in the
+    // MAXPY pass, the Givens step of iteration j-1 inside the head kernel of iteration j
     const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR;
     const int m = c->m;
     const int32_t nl = c->n_local;
-    double *y1b = c->y1tmp.p, *x1b = c->y1tmp.p + 16, *w1b = c->y1tmp.p + 32;
-    auto prep_for = [&](const double *wvec) {
-        k::SchurPrep p{};
-        p.m = fused ? m : 0;
-        p.fact = c->schur_fact;
-        p.w1 = wvec + nl;
-        p.traw = sm + 65;
-        p.shat = c->shat.p;
-        p.gram = c->gram.p;
-        p.y1 = y1b;
-        p.x1 = x1b;
-        p.w1next = w1b;
-        return p;
-    };
+    const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
+    const double *bdp = fused ? c->bd.p : nullptr;
 
     KrylovState st{};
     int cycles = 0;
     for (;;) {
-        // ---- cycle start: ||r||, convergence test, v0 = r/||r|| ----
-        if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, c->fin(sm + 64), done, s);
-        else k::sqnorm(Vj(0), n_dot, c->fin(sm + 64), done, s);
-        c->comm->allreduce_sum(sm + 64, fused ? 1 + m : 1, s);
-        k::krylov_cycle_begin(c->ka, sm + 64, prep_for(Vj(0)), s);
+        // ---- cycle start: ||r|| (parity slot 1 = "iteration -1"), convergence test, v0 = r/||r|| ----
+        if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
+        else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
+        c->comm->allreduce_sum(nrmbuf(1), nn, s);
+        k::krylov_cycle_begin(c->ka, nrmbuf(1), s);
         if (!fused) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
+        int last = -1;  // last iteration of this cycle whose Givens step is still pending (fused path)
         for (int loc = 0; loc < mk && !stop; ++loc) {
             double *w = Vj(loc + 1);
+            double *db = dotsbuf(loc), *nb = nrmbuf(loc);
             if (fused) {
-                // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part)
-                k::fused_scale_pc(Vj(loc), inv_tt, c->dinv.p, c->bd.p, ld, prep_for(Vj(loc)), nl, Zj(loc), w, done, s);
-                // w += A z0 (halo exchange inside op_mult is bypassed: do it here)
+                // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part);
+                // workgroup 0 also runs the Givens step of iteration loc-1
+                k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
+                              c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s);
+                last = loc;
+                // w += A z0
                 if (c->n_ghost > 0) {
                     k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
@@ -490,45 +490,48 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
             }
-            const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY
-            const double *bdp = fused ? c->bd.p : nullptr;
             if (o.orthog == SPK_ORTHOG_MGS) {
                 // KSPGMRESModifiedGramSchmidtOrthogonalization: one dot + one axpy per basis vector
                 for (int j = 0; j <= loc; ++j) {
-                    k::mdot(Vj(j), ld, 1, w, N, n_dot, c->fin(sm + j), done, s);
-                    c->comm->allreduce_sum(sm + j, 1, s);
+                    k::mdot(Vj(j), ld, 1, w, N, n_dot, c->fin(db + j), done, s);
+                    c->comm->allreduce_sum(db + j, 1, s);
                     const bool lastv = j == loc;
-                    k::maxpy(Vj(j), ld, 1, nullptr, sm + j, -1.0, w, N, n_dot, c->fin(lastv ? sm + 64 : nullptr), done, s,
-                             lastv ? bdp : nullptr, ld, nl, m);
+                    k::maxpy(Vj(j), ld, 1, nullptr, db + j, -1.0, w, N, n_dot, c->fin(lastv ? nb : nullptr), done, s,
+                             lastv ? bdp : nullptr, ld, nl, m, lastv && fused ? w1side : nullptr);
                 }
-                c->comm->allreduce_sum(sm + 64, nn, s);
+                c->comm->allreduce_sum(nb, nn, s);
             } else {
-                // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 in the same pass)
-                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm), done, s);
-                c->comm->allreduce_sum(sm, loc + 2, s);
-                k::maxpy(V, ld, loc + 1, nullptr, sm, -1.0, w, N, n_dot, c->fin(sm + 64), done, s, bdp, ld, nl, m);
-                c->comm->allreduce_sum(sm + 64, nn, s);
+                // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
+                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s);
+                c->comm->allreduce_sum(db, loc + 2, s);
+                k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nb), done, s, bdp, ld, nl, m,
+                         fused ? w1side : nullptr);
+                c->comm->allreduce_sum(nb, nn, s);
                 if (o.cgs_refine != SPK_REFINE_NEVER) {
                     // second pass on the device's own decision (-ksp_gmres_cgs_refinement_type)
                     const int32_t *skip = &c->kst.p->skip_refine;
-                    double *sm2 = sm + 192, *nb = sm + 320;
-                    k::krylov_refine_decide(c->ka, loc, o.cgs_refine, sm, sm + 64, sm2, s);
+                    k::krylov_refine_decide(c->ka, loc, o.cgs_refine, db, nb, sm2, s);
                     k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm2), skip, s);
                     c->comm->allreduce_sum(sm2, loc + 2, s);
-                    k::maxpy(V, ld, loc + 1, nullptr, sm2, -1.0, w, N, n_dot, c->fin(nb), skip, s, bdp, ld, nl, m);
-                    c->comm->allreduce_sum(nb, nn, s);
-                    k::krylov_refine_merge(c->ka, loc, sm, sm2, sm + 64, nb, nn, s);
+                    k::maxpy(V, ld, loc + 1, nullptr, sm2, -1.0, w, N, n_dot, c->fin(nrm2b), skip, s, bdp, ld, nl, m,
+                             fused ? w1side : nullptr);
+                    c->comm->allreduce_sum(nrm2b, nn, s);
+                    k::krylov_refine_merge(c->ka, loc, db, sm2, nb, nrm2b, nn, s);
                 }
             }
-            // Hessenberg column, Givens, convergence (+ the next apply's m-vector data) -- on the device
-            k::krylov_givens(c->ka, loc, sm, sm + 64, prep_for(w), s);
-            if (!fused) k::scale_dev(w, N, inv_tt, done, s);  // v_{j+1} = w / ||w||
+            if (!fused) {
+                // Hessenberg column, Givens, convergence -- on the device; then v_{j+1} = w / ||w||
+                k::krylov_givens(c->ka, loc, db, nb, s);
+                k::scale_dev(w, N, inv_tt, done, s);
+            }
             if (o.check_every > 0 && (loc + 1) % o.check_every == 0 && loc + 1 < mk) {
                 SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
                 SPK_HIP(hipStreamSynchronize(s));
-                stop = st.done != 0;
+                stop = st.done != 0;  // fused path: lags by one iteration, the iterate does not care
             }
         }
+        // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
+        if (fused && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
         k::krylov_cycle_end(c->ka, s);
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
