@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--cpu-its", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound on the CPU baseline sample")
     ap.add_argument("--spmv-reps", type=int, default=200)
+    ap.add_argument("--single-reduce", type=int, default=0, help="0 auto (on when N > 1), 1 on, 2 off")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +155,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300)
+    kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300, single_reduce=args.single_reduce)
     # ---- warm-up: W untimed iterations
     if args.warmup > 0:
         ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
@@ -211,6 +212,8 @@ def main():
                                + ("saddle K=[A B^T;B 0] with 4 constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (4 if saddle else 0), "pc": args.pc, "restart": args.restart,
+                   "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
+                                                     (args.single_reduce == 1 or (args.single_reduce == 0 and world > 1))) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},
         "spmv_gbps": achieved,
         "spmv_ms": spmv_ms,

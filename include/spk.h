@@ -86,7 +86,10 @@ typedef struct spk_opts {
     int32_t fused;          /* 1: fused PC+operator kernels where the PC allows,
                                0: PCApply and MatMult as separate steps */
     int32_t cgs_refine;     /* -ksp_gmres_cgs_refinement_type: SPK_REFINE_* (never) */
-    int32_t reserved[3];
+    int32_t single_reduce;  /* fused CGS only: h = V^T w, B D w and w.w from ONE pass and ONE
+                               all-reduce; ||w'||^2 = w.w - |h|^2 and B D w' by recurrence.
+                               0 = automatic (on when ranks > 1), 1 = on, 2 = off */
+    int32_t reserved[2];
 } spk_opts;
 
 typedef struct spk_result {

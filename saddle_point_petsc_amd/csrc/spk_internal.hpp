@@ -193,16 +193,23 @@ void scatter_row(const int32_t *colidx, const double *val, int k0, int k1, const
                  double *dense, hipStream_t s);
 // out[i] = sum_r slots[r*ld + i] in rank order (local-group all-reduce)
 void sum_slots(const double *slots, int nslots, int ld, int count, double *out, hipStream_t s);
-// f.out[i] = V_i . w for i < nv, f.out[nv] = w.w
+// f.out[i] = V_i . w for i < nv, then V2_i . w for i < nv2 (second slab, same stride), then w.w
 void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
-          const Finish &f, const int32_t *done, hipStream_t s);
+          const Finish &f, const int32_t *done, hipStream_t s, const double *V2 = nullptr, int nv2 = 0);
+// single-reduction Gram-Schmidt: scalars derived by workgroup 0 of the MAXPY kernel
+struct PythArgs {
+    int m;               // < 0: off
+    const double *dots;  // [h_0..h_{nv-1}, q_0..q_{m-1}, w.w]  (reduced)
+    double *tb;          // (restart+2) x 8: B D v_i per basis vector
+    double *nrm_out;     // [||w'||^2, B D w' (m)]
+};
 // w += sign * sum_i a[i] * V_i ; f.out[0] = ||w_new||^2 over the first n_dot entries
 // (f.out == nullptr: no norm)
 // with bd != nullptr also f.out[1+r] = sum_i bd[i*MP + r] * w_new[i], i < n_bd (fused Schur path)
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
            const int32_t *done, hipStream_t s, const double *bd = nullptr, int64_t ldb = 0, int64_t n_bd = 0, int m = 0,
-           double *w1side = nullptr);
+           double *w1side = nullptr, const PythArgs *pyth = nullptr);
 void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *bd, hipStream_t s);
 void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
                double *w1side, const Finish &f, const int32_t *done, hipStream_t s);
@@ -229,11 +236,11 @@ void copy_small(const double *src, double *dst, int n, const int32_t *done, hipS
 // Krylov scalar kernels (single wave)
 struct KrylovArrays {
     KrylovState *st;
-    double *H, *cc, *ss, *rs, *nrs, *hcol, *hist;
+    double *H, *cc, *ss, *rs, *nrs, *hcol, *hist, *tb;
     int32_t hist_cap, ldh;
 };
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s);
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0);
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
 // head of a fused Schur iteration: VecScale + PCApply + B^T part of MatMult in one pass, plus the
 // previous iteration's Givens step in workgroup 0 (loc_prev < 0: none)

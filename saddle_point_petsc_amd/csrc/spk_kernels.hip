@@ -501,6 +501,7 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t i2)
 // arithmetic, set the rate of this kernel).
 template <int NG, int T, int G, bool NT, int U>
 __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, int64_t ldv, int nv,
+                                                 const double *__restrict__ V2, int nv1,
                                                  const double *__restrict__ w, int64_t n2,
                                                  int64_t n_dot, double *__restrict__ partials,
                                                  int with_ww, unsigned *__restrict__ counter,
@@ -539,7 +540,8 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
                     const int ic = (g0 + v < nv) ? g0 + v : nv - 1;  // clamp: re-reads a cached vector
-                    const double *Vi = V + (size_t)ic * ldv;
+                    // vectors nv1.. come from a second slab (the rows of B D in the single-reduction mode)
+                    const double *Vi = ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(ic - nv1) * ldv;
 #pragma unroll
                     for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, idx[u]);
                 }
@@ -605,39 +607,49 @@ static int vec_grid(int64_t n2, int T = kVT)
 }
 
 template <int T, int U>
-static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *w,
-                        int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo, const int32_t *done)
+static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *V2, int nv1,
+                        const double *w, int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo,
+                        const int32_t *done)
 {
+#define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
+                                         n2, n_dot, pp, last, cn, oo, done)
     switch (ng) {
-    case 1: hipLaunchKernelGGL((mdot_kernel<1, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-    case 2: hipLaunchKernelGGL((mdot_kernel<2, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-    case 3: hipLaunchKernelGGL((mdot_kernel<3, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
-    default: hipLaunchKernelGGL((mdot_kernel<4, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done); break;
+    case 1: SPK_MDOT(1); break;
+    case 2: SPK_MDOT(2); break;
+    case 3: SPK_MDOT(3); break;
+    case 4: SPK_MDOT(4); break;
+    default: SPK_MDOT(5); break;
     }
+#undef SPK_MDOT
 }
 
 void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
-          const Finish &f, const int32_t *done, hipStream_t s)
+          const Finish &f, const int32_t *done, hipStream_t s, const double *V2, int nv2)
 {
-    if (nv > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: nv=%d exceeds %d", nv, kMaxNv - 1);
+    // nv vectors from V, then nv2 from V2 (same stride); results in that order, w.w last
+    const int ntot = nv + nv2;
+    if (ntot > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: %d vectors exceed %d", ntot, kMaxNv - 1);
     const int64_t n2 = (n + 1) / 2;
     const VecShape vs = vec_shape(n2);
-    // up to 32 vectors per launch; w.w is produced by the last launch
+    // up to 40 vectors per launch; w.w is produced by the last launch
     int v0 = 0;
     do {
-        const int cnt = (nv - v0) < 32 ? (nv - v0) : 32;
-        const int last = (v0 + 32 >= nv);
+        const int cnt = (ntot - v0) < 40 ? (ntot - v0) : 40;
+        const int last = (v0 + 40 >= ntot);
+        // vector i of this launch is V[v0+i] while v0+i < nv, else V2[v0+i-nv]
         const double *Vp = V + (size_t)v0 * ldv;
+        const int nv1 = nv - v0 > 0 ? nv - v0 : 0;
+        const double *V2p = nv1 > 0 ? V2 : V2 + (size_t)(v0 - nv) * ldv;
         double *pp = f.partials + v0;
         double *oo = f.out + v0;
         unsigned *cn = f.counter;
-        const int ng = cnt <= 8 ? 1 : cnt <= 16 ? 2 : cnt <= 24 ? 3 : 4;
-        if (vs.T == 512) mdot_launch<512, 4>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
-        else if (vs.U == 4) mdot_launch<256, 4>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
-        else if (vs.U == 2) mdot_launch<256, 2>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
-        else mdot_launch<256, 1>(ng, vs.grid, s, Vp, ldv, cnt, w, n2, n_dot, pp, last, cn, oo, done);
-        v0 += 32;
-    } while (v0 < nv);
+        const int ng = (cnt + 7) / 8 > 0 ? (cnt + 7) / 8 : 1;
+        if (vs.T == 512) mdot_launch<512, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
+        else if (vs.U == 4) mdot_launch<256, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
+        else if (vs.U == 2) mdot_launch<256, 2>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
+        else mdot_launch<256, 1>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
+        v0 += 40;
+    } while (v0 < ntot);
 }
 
 // ---------------------------------------------------------------------------
@@ -655,11 +667,38 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          double *__restrict__ out,
                                                          const double *__restrict__ bd, int64_t ldb,
                                                          int64_t n_bd, int m, double *__restrict__ w1side,
-                                                         const int32_t *__restrict__ done)
+                                                         PythArgs py, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     if (nv_dev) nv = *nv_dev;
     constexpr int NR = MP + 1, W = T / kWave;
+    if (py.m >= 0 && blockIdx.x == 0 && threadIdx.x < kWave) {
+        // single-reduction mode: the norm and B D w' of the vector this kernel is about to
+        // build follow from the ONE reduced set {h = V^T w, q = B D w, w.w}:
+        //   ||w'||^2 = w.w - sum h_i^2          (w' = w - V h, V orthonormal)
+        //   B D w'   = q - sum h_i (B D v_i)    (tb[i] = B D v_i, kept per basis vector)
+        // first wave of workgroup 0, lane i owns basis vector i (nv <= 63)
+        const int i = threadIdx.x;
+        const double hi = i < nv ? py.dots[i] : 0.0;
+        const double hh = wave_sum(hi * hi);
+        double tsum[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tsum[r] = r < py.m ? wave_sum(i < nv ? hi * py.tb[i * 8 + r] : 0.0) : 0.0;
+        if (i == 0) {
+            double tt2 = py.dots[nv + py.m] - hh;
+            if (!(tt2 > 0.0)) tt2 = 0.0;
+            py.nrm_out[0] = tt2;
+            const double inv = tt2 > 0.0 ? 1.0 / sqrt(tt2) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < py.m) {
+                    const double t = py.dots[nv + r] - tsum[r];
+                    py.nrm_out[1 + r] = t;
+                    py.tb[nv * 8 + r] = t * inv;
+                }
+            }
+        }
+    }
     __shared__ double red[(W * NR > T) ? W * NR : T];
     __shared__ int last;
     double nrm = 0.0;
@@ -711,7 +750,7 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                 }
             }
         }
-        if (MP > 0) {
+        if (MP > 0 && bd) {
             // traw[r] += (B D)_r . w_new over the u rows; B D is stored PLANAR (row r = one dense
             // vector of stride ldb), so these are m more perfectly coalesced streams
 #pragma unroll
@@ -759,10 +798,11 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
 template <int T, int U>
 static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64_t ldv, int nv, const int32_t *nv_dev,
                          const double *a, double sign, double *w, int64_t n2, int64_t n_dot, const Finish &f,
-                         const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side, const int32_t *done)
+                         const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side, const PythArgs &py,
+                         const int32_t *done)
 {
 #define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, 4, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, done)
+                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, py, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
     else SPK_MAXPY(0);
@@ -771,15 +811,20 @@ static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64
 
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
-           const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side)
+           const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side,
+           const PythArgs *pyth)
 {
     const int64_t n2 = (n + 1) / 2;
     const VecShape vs = vec_shape(n2);
-    const int mp = (bd && m > 0) ? (m <= 4 ? 4 : 8) : 0;
-    if (vs.T == 512) maxpy_launch<512, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
-    else if (vs.U == 4) maxpy_launch<256, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
-    else if (vs.U == 2) maxpy_launch<256, 2>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
-    else maxpy_launch<256, 1>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, done);
+    PythArgs py{};
+    py.m = -1;
+    if (pyth) py = *pyth;
+    // MP > 0 also switches on the lambda side copy; in single-reduction mode bd is not read
+    const int mp = ((bd || pyth) && m > 0) ? (m <= 4 ? 4 : 8) : 0;
+    if (vs.T == 512) maxpy_launch<512, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
+    else if (vs.U == 4) maxpy_launch<256, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
+    else if (vs.U == 2) maxpy_launch<256, 2>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
+    else maxpy_launch<256, 1>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1137,7 +1182,7 @@ void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2
     hipLaunchKernelGGL(krylov_init_kernel, dim3(1), dim3(64), 0, s, ka, o, bnorm2);
 }
 
-__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2)
+__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, double *tb, int m)
 {
     if (threadIdx.x != 0) return;
     KrylovState *st = ka.st;
@@ -1159,10 +1204,12 @@ __global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2)
     }
     ka.rs[0] = rnorm;
     st->inv_tt = 1.0 / rnorm;
+    if (tb)  // B D v_0 for the single-reduction recurrence
+        for (int r = 0; r < m; ++r) tb[r] = nrm2[1 + r] / rnorm;
 }
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s)
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb, int m)
 {
-    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2);
+    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, tb, m);
 }
 
 // One Arnoldi step's scalar work (KSPFGMRESUpdateHessenberg + KSPConvergedDefault), run by a

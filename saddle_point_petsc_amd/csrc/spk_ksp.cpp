@@ -212,6 +212,8 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
         } else if (key == "-fieldsplit_0_pc_type" || key == "-fieldsplit_1_pc_type") {
             if (!val) return need("a type");
             if (std::string(val) != "jacobi") return bad();
+        } else if (key == "-spk_single_reduce") {
+            if (!val || !parse_int(val, &k->opts.single_reduce)) return need("an integer (0 auto, 1 on, 2 off)");
         } else if (key == "-spk_check_every") {
             if (!val || !parse_int(val, &k->opts.check_every)) return need("an integer");
         } else if (key.rfind("-ksp_", 0) == 0 || key.rfind("-pc_", 0) == 0 || key.rfind("-fieldsplit_", 0) == 0) {

@@ -389,7 +389,7 @@ static void ensure_krylov(spk_ctx *c, const spk_opts &o)
         c->ws_restart = mk;
     }
     const int ldh = mk + 2;
-    const size_t nd = (size_t)ldh * (mk + 1) + 4 * (size_t)(mk + 2) + (size_t)hist_cap + 64;
+    const size_t nd = (size_t)ldh * (mk + 1) + 4 * (size_t)(mk + 2) + 8 * (size_t)(mk + 2) + (size_t)hist_cap + 64;
     if (c->kry_d.n < nd) c->kry_d.alloc(nd);
     if (!c->kst.p) c->kst.alloc(1);
     double *p = c->kry_d.p;
@@ -401,6 +401,7 @@ static void ensure_krylov(spk_ctx *c, const spk_opts &o)
     c->ka.rs = p;     p += mk + 2;
     c->ka.nrs = p;    p += mk + 2;
     c->ka.hcol = nullptr;
+    c->ka.tb = p;     p += 8 * (size_t)(mk + 2);
     c->ka.hist = p;
     c->ka.hist_cap = hist_cap;
 }
@@ -456,6 +457,12 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const int32_t nl = c->n_local;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
     const double *bdp = fused ? c->bd.p : nullptr;
+    // single-reduction Gram-Schmidt (fused CGS without refinement): h = V^T w, q = B D w and w.w
+    // come out of ONE pass and ONE all-reduce; ||w'||^2 = w.w - |h|^2 and B D w' = q - sum h_i B D v_i
+    // follow without touching w' -- one collective per iteration instead of two.
+    // opts.single_reduce: 0 = automatic (on when there is more than one rank), 1 = on, 2 = off.
+    const bool single = fused && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
+                        (o.single_reduce == 1 || (o.single_reduce == 0 && c->comm->size() > 1));
 
     KrylovState st{};
     int cycles = 0;
@@ -464,7 +471,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
         else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
-        k::krylov_cycle_begin(c->ka, nrmbuf(1), s);
+        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, single ? c->ka.tb : nullptr, m);
         if (!fused) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
@@ -500,6 +507,12 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                              lastv ? bdp : nullptr, ld, nl, m, lastv && fused ? w1side : nullptr);
                 }
                 c->comm->allreduce_sum(nb, nn, s);
+            } else if (single) {
+                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s, c->bd.p, m);
+                c->comm->allreduce_sum(db, loc + 2 + m, s);
+                k::PythArgs py{m, db, c->ka.tb, nb};
+                k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nullptr), done, s, nullptr, ld, nl, m,
+                         w1side, &py);
             } else {
                 // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
                 k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s);

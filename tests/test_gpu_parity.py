@@ -210,6 +210,26 @@ def test_orthogonalisation_options(spk, oracle, kw, fused):
     assert relerr(x, xo) < 1e-8
 
 
+@pytest.mark.parametrize("fact", [1, 3])
+def test_single_reduction_gram_schmidt(spk, oracle, fact):
+    """opts.single_reduce = 1: one reduction per iteration (||w'||^2 = w.w - |h|^2, B D w' by
+    recurrence) against the two-reduction fused path and the oracle."""
+    A, f = spk.AssembleOperator_Laplace(40, 28)
+    B, g = spk.AssembleOperator_Constraints(40, 28)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, fact)
+        x1, i1 = c.fgmres(rhs, rtol=1e-10, single_reduce=1)
+        x2, i2 = c.fgmres(rhs, rtol=1e-10, single_reduce=2)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=fact, rtol=1e-10)
+    assert i1["reason"] == i2["reason"] == 2
+    assert abs(i1["its"] - i2["its"]) <= 1 and abs(i1["its"] - io["its"]) <= 1
+    assert np.allclose(i1["history"][:21], i2["history"][:21], rtol=1e-9)
+    assert relerr(x1, x2) < 1e-8 and relerr(x1, xo) < 1e-8
+
+
 def test_fgmres_rtol_1e8_iteration_counts(spk, golden_m32):
     A, f = spk.AssembleOperator_Laplace(32)
     B, g = spk.AssembleOperator_Constraints(32)
