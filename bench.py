@@ -87,13 +87,15 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--grid", type=int, default=1024, help="DMDA nodes per side")
+    ap.add_argument("--grid-y", type=int, default=0, help="node lines in y (default: square); e.g. 128 emulates one "
+                                                          "rank's slab of the 8-GPU split on one GPU")
     ap.add_argument("--pc", default="schur-full", choices=["schur-full", "schur-lower", "schur-upper", "schur-diag", "jacobi"])
     ap.add_argument("--restart", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-its", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound on the CPU baseline sample")
     ap.add_argument("--spmv-reps", type=int, default=200)
-    ap.add_argument("--single-reduce", type=int, default=0, help="0 auto (on when N > 1), 1 on, 2 off")
+    ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,14 +126,15 @@ def main():
     import saddle_point_petsc_amd as S   # fails loudly if libspk.so is not built
 
     M = args.grid
-    n, nnz_global = S.grid_sizes(M)
+    My = args.grid_y or M
+    n, nnz_global = S.grid_sizes(M, My)
     t_setup = time.time()
-    rb, re_ = S.partition_slab(M, M, rank, world)
-    A, f = S.AssembleOperator_Laplace(M, M, rb, re_)
+    rb, re_ = S.partition_slab(M, My, rank, world)
+    A, f = S.AssembleOperator_Laplace(M, My, rb, re_)
     saddle = args.pc != "jacobi"
     B = g = None
     if saddle:
-        B, g = S.AssembleOperator_Constraints(M, M, rb, re_)
+        B, g = S.AssembleOperator_Constraints(M, My, rb, re_)
     ctx = S.Context(local_rank)
     if use_dist:
         ids = [S.unique_id() if rank == 0 else None]
@@ -181,7 +184,7 @@ def main():
     achieved_layout = spi["layout_bytes"] / (spmv_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-    if os.path.exists(tpath) and world == 1 and M == 1024:
+    if os.path.exists(tpath) and world == 1 and M == 1024 and My == 1024:
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_" + ctx.spmv_info()["format"])
         except Exception:  # noqa: BLE001
@@ -208,12 +211,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{M}x{M} DMDA node grid, dof 2 (n={n}, nnz(A)={nnz_global}), "
+        "config": {"workload": f"{M}x{My} DMDA node grid, dof 2 (n={n}, nnz(A)={nnz_global}), "
                                + ("saddle K=[A B^T;B 0] with 4 constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (4 if saddle else 0), "pc": args.pc, "restart": args.restart,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
-                                                     (args.single_reduce == 1 or (args.single_reduce == 0 and world > 1))) else 2,
+                                                     args.single_reduce == 1) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},
         "spmv_gbps": achieved,
         "spmv_ms": spmv_ms,
@@ -257,7 +260,7 @@ def main():
         tc = time.perf_counter() - t0
         t_spmv = O.time_spmv(Ao, 5, cores) / 5
         out["cpu_baseline"] = {"value": io["its"] / tc, "unit": "iterations/s", "cores": cores, "kind": "port",
-                               "sample": f"{io['its']} FGMRES iterations (first restart cycle) of the same {M}x{M} "
+                               "sample": f"{io['its']} FGMRES iterations (first restart cycle) of the same {M}x{My} "
                                          f"system with the oracle, OpenMP over {cores} threads",
                                "spmv_gbps": spmv_bytes(A.nrows, A.nnz) / t_spmv / 1e9,
                                "label": "PETSc-equivalent CPU restatement (PETSc not installable offline)"}

@@ -86,9 +86,13 @@ typedef struct spk_opts {
     int32_t fused;          /* 1: fused PC+operator kernels where the PC allows,
                                0: PCApply and MatMult as separate steps */
     int32_t cgs_refine;     /* -ksp_gmres_cgs_refinement_type: SPK_REFINE_* (never) */
-    int32_t single_reduce;  /* fused CGS only: h = V^T w, B D w and w.w from ONE pass and ONE
-                               all-reduce; ||w'||^2 = w.w - |h|^2 and B D w' by recurrence.
-                               0 = automatic (on when ranks > 1), 1 = on, 2 = off */
+    int32_t single_reduce;  /* fused CGS only, OFF by default: 1 = h = V^T w, B D w and w.w from ONE
+                               pass and ONE all-reduce per iteration; ||w'||^2 = w.w - |h|^2 and
+                               B D w' by recurrence.  Saves a collective per iteration on many
+                               GPUs but the subtraction cancels (||w'|| << ||w|| behind a good
+                               preconditioner): measured 5e-6 relative drift of the residual
+                               history inside the first cycle at 1024^2 (two-reduction path:
+                               3e-11), converged solutions still agree to the tolerance. */
     int32_t reserved[2];
 } spk_opts;
 

@@ -114,15 +114,17 @@ __device__ __forceinline__ void final_reduce(const double *partials, int nb, int
     const int i = threadIdx.x & (kk - 1), sl = threadIdx.x / kk, nsl = T / kk;
     double acc = 0.0;
     if (i < k) {
-        for (int b0 = sl; b0 < nb; b0 += nsl * 8) {
-            double v[8];
+        // all of a thread's partials are requested before the first add: one memory round trip
+        // (each is an sc1 load that misses L2) instead of one per batch
+        for (int b0 = sl; b0 < nb; b0 += nsl * 32) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int b = b0 + u * nsl;
                 v[u] = b < nb ? peek(partials + (size_t)b * ld + i) : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < 32; ++u) acc += v[u];
         }
     }
     scratch[sl * kk + i] = acc;

@@ -213,7 +213,7 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
             if (!val) return need("a type");
             if (std::string(val) != "jacobi") return bad();
         } else if (key == "-spk_single_reduce") {
-            if (!val || !parse_int(val, &k->opts.single_reduce)) return need("an integer (0 auto, 1 on, 2 off)");
+            if (!val || !parse_int(val, &k->opts.single_reduce)) return need("an integer (0 off, 1 on)");
         } else if (key == "-spk_check_every") {
             if (!val || !parse_int(val, &k->opts.check_every)) return need("an integer");
         } else if (key.rfind("-ksp_", 0) == 0 || key.rfind("-pc_", 0) == 0 || key.rfind("-fieldsplit_", 0) == 0) {

@@ -460,9 +460,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // single-reduction Gram-Schmidt (fused CGS without refinement): h = V^T w, q = B D w and w.w
     // come out of ONE pass and ONE all-reduce; ||w'||^2 = w.w - |h|^2 and B D w' = q - sum h_i B D v_i
     // follow without touching w' -- one collective per iteration instead of two.
-    // opts.single_reduce: 0 = automatic (on when there is more than one rank), 1 = on, 2 = off.
+    // Opt-in (opts.single_reduce = 1): the subtraction cancels, see include/spk.h.
     const bool single = fused && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
-                        (o.single_reduce == 1 || (o.single_reduce == 0 && c->comm->size() > 1));
+                        o.single_reduce == 1;
 
     KrylovState st{};
     int cycles = 0;

