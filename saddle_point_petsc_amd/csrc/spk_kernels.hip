@@ -285,7 +285,7 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 // block land in LDS as (a00 x0, a01 x1, a10 x0, a11 x1); row 2k adds its pairs in block
 // order = CSR order, so the result is bit-identical to the CSR kernel and the oracle.
 // ---------------------------------------------------------------------------
-constexpr int kBTile = 512;  // blocks per tile (2048 stored non-zeros)
+static int bcsr_tile() { static const int t = env_int("SPK_BCSR_TILE", 512); return t; }  // blocks per tile
 
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow)
 {
@@ -294,12 +294,13 @@ void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &
     int32_t r = 0;
     while (r < nbrows) {
         const int32_t r0 = r;
-        while (r < nbrows && (r - r0) < 128 && (browptr[r + 1] - browptr[r0]) <= kBTile) ++r;
+        while (r < nbrows && (r - r0) < 128 && (browptr[r + 1] - browptr[r0]) <= bcsr_tile()) ++r;
         if (r == r0) ++r;  // block row longer than a tile: handled by the strided path
         tile_brow.push_back(r);
     }
 }
 
+template <int kBTile, bool NT>
 __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
     const double *__restrict__ vtop, const double *__restrict__ vbot,
@@ -343,16 +344,16 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
         return;
     }
 
-    constexpr int kSteps = kBTile / kThreads;  // 2
+    constexpr int kSteps = kBTile / kThreads;
     int c[kSteps];
     double2 tp[kSteps], bo[kSteps];
 #pragma unroll
     for (int i = 0; i < kSteps; ++i) {
         const int q = i * kThreads + threadIdx.x;
         if (q < cnt) {
-            c[i] = bcol[b0 + q];
-            tp[i] = reinterpret_cast<const double2 *>(vtop)[b0 + q];
-            bo[i] = reinterpret_cast<const double2 *>(vbot)[b0 + q];
+            c[i] = NT ? __builtin_nontemporal_load(bcol + b0 + q) : bcol[b0 + q];
+            tp[i] = ld2s<NT>(vtop, b0 + q);
+            bo[i] = ld2s<NT>(vbot, b0 + q);
         }
     }
 #pragma unroll
@@ -394,9 +395,15 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
 {
     if (A.nbrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
-    hipLaunchKernelGGL(spmv_bcsr_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, A.vtop.p,
-                       A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done);
+    static const int nt = env_int("SPK_BCSR_NT", 1);  // nt on the matrix planes: 70.7 -> 61.3 us (same run)
+#define SPK_BCSR(TL, NTT) hipLaunchKernelGGL((spmv_bcsr_kernel<TL, NTT>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
+                       A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,            \
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done)
+    const int tl = bcsr_tile();
+    if (tl == 256) { if (nt) SPK_BCSR(256, true); else SPK_BCSR(256, false); }
+    else if (tl == 1024) { if (nt) SPK_BCSR(1024, true); else SPK_BCSR(1024, false); }
+    else { if (nt) SPK_BCSR(512, true); else SPK_BCSR(512, false); }
+#undef SPK_BCSR
 }
 
 // compressed off-rank block: few short rows, one thread per row
