@@ -147,19 +147,14 @@ __device__ __forceinline__ void reset_counter(unsigned *counter)
 // the same order and roundings as a sequential CSR loop.
 // Arrays are padded by >= 8 entries so whole quads can be loaded unguarded.
 // ---------------------------------------------------------------------------
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-// nnz per tile / threads per workgroup of the stream kernel (tunable for experiments)
-static int spmv_tile_nnz() { static const int t = env_int("SPK_SPMV_TILE", 2048); return t; }
-static int spmv_threads() { static const int t = env_int("SPK_SPMV_T", 256); return t; }
+// Stored non-zeros per tile of the CSR stream kernel.  Measured at M = 1024 (same run):
+// 4096 -> 99.9 us, 2048 -> 87.1 us, 1024 -> 87.3 us, 512 (one wave per tile) -> 86.4 us;
+// non-temporal loads on the matrix stream: 102 us (slower; not used for CSR).
+constexpr int kCsrTile = 2048;
 
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row)
 {
-    const int kTileNnz = spmv_tile_nnz(), kTileRows = spmv_threads();
+    const int kTileNnz = kCsrTile, kTileRows = kThreads;
     tile_row.clear();
     tile_row.push_back(0);
     int32_t r = 0;
@@ -259,24 +254,9 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 {
     if (A.nrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
-    static const int nt = env_int("SPK_SPMV_NT", 0);
-#define SPK_SPMV(TILE, T) if (nt) SPK_SPMV_(true, TILE, T); else SPK_SPMV_(false, TILE, T)
-#define SPK_SPMV_(NT, TILE, T) hipLaunchKernelGGL((spmv_stream_kernel<NT, TILE, T>), dim3(tpx * 8), dim3(T), 0, s, A.rowptr.p, \
-                                             A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y,                  \
-                                             bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr,                \
-                                             bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done)
-    const int tile = spmv_tile_nnz(), T = spmv_threads();
-    if (tile == 4096 && T == 256) { SPK_SPMV(4096, 256); }
-    else if (tile == 2048 && T == 256) { SPK_SPMV(2048, 256); }
-    else if (tile == 1024 && T == 256) { SPK_SPMV(1024, 256); }
-    else if (tile == 2048 && T == 128) { SPK_SPMV(2048, 128); }
-    else if (tile == 1024 && T == 128) { SPK_SPMV(1024, 128); }
-    else if (tile == 1024 && T == 64) { SPK_SPMV(1024, 64); }
-    else if (tile == 512 && T == 128) { SPK_SPMV(512, 128); }
-    else if (tile == 512 && T == 64) { SPK_SPMV(512, 64); }
-    else fail(SPK_ERR_ARG, "unsupported SPK_SPMV_TILE/SPK_SPMV_T combination %d/%d", tile, T);
-#undef SPK_SPMV
-#undef SPK_SPMV_
+    hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads>), dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p,
+                       A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done);
 }
 
 // ---------------------------------------------------------------------------
@@ -285,7 +265,8 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 // block land in LDS as (a00 x0, a01 x1, a10 x0, a11 x1); row 2k adds its pairs in block
 // order = CSR order, so the result is bit-identical to the CSR kernel and the oracle.
 // ---------------------------------------------------------------------------
-static int bcsr_tile() { static const int t = env_int("SPK_BCSR_TILE", 512); return t; }  // blocks per tile
+// blocks per tile (2048 stored non-zeros); measured 256: 63.6 us, 512: 61.3 us, 1024: 76.2 us
+constexpr int kBTile = 512;
 
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow)
 {
@@ -294,13 +275,13 @@ void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &
     int32_t r = 0;
     while (r < nbrows) {
         const int32_t r0 = r;
-        while (r < nbrows && (r - r0) < 128 && (browptr[r + 1] - browptr[r0]) <= bcsr_tile()) ++r;
+        while (r < nbrows && (r - r0) < 128 && (browptr[r + 1] - browptr[r0]) <= kBTile) ++r;
         if (r == r0) ++r;  // block row longer than a tile: handled by the strided path
         tile_brow.push_back(r);
     }
 }
 
-template <int kBTile, bool NT>
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
     const double *__restrict__ vtop, const double *__restrict__ vbot,
@@ -395,15 +376,10 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
 {
     if (A.nbrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
-    static const int nt = env_int("SPK_BCSR_NT", 1);  // nt on the matrix planes: 70.7 -> 61.3 us (same run)
-#define SPK_BCSR(TL, NTT) hipLaunchKernelGGL((spmv_bcsr_kernel<TL, NTT>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
-                       A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,            \
-                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done)
-    const int tl = bcsr_tile();
-    if (tl == 256) { if (nt) SPK_BCSR(256, true); else SPK_BCSR(256, false); }
-    else if (tl == 1024) { if (nt) SPK_BCSR(1024, true); else SPK_BCSR(1024, false); }
-    else { if (nt) SPK_BCSR(512, true); else SPK_BCSR(512, false); }
-#undef SPK_BCSR
+    // non-temporal loads on the matrix planes (read once per SpMV): 70.7 -> 61.3 us in the same run
+    hipLaunchKernelGGL((spmv_bcsr_kernel<true>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, A.vtop.p,
+                       A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done);
 }
 
 // compressed off-rank block: few short rows, one thread per row
@@ -548,11 +524,14 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                 double2 a[G][U];
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
-                    const int ic = (g0 + v < nv) ? g0 + v : nv - 1;  // clamp: re-reads a cached vector
+                    // a slot past nv loads ONE broadcast address (w[0..1], weight 0) instead of a
+                    // vector tile: the group stays branch-free and costs no bandwidth
+                    const bool live = g0 + v < nv;
+                    const int ic = live ? g0 + v : 0;
                     // vectors nv1.. come from a second slab (the rows of B D in the single-reduction mode)
-                    const double *Vi = ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(ic - nv1) * ldv;
+                    const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(ic - nv1) * ldv);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, idx[u]);
+                    for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, live ? idx[u] : 0);
                 }
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
@@ -731,11 +710,12 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
             double ai[G];
 #pragma unroll
             for (int v = 0; v < G; ++v) {
-                const int ic = (g0 + v < nv) ? g0 + v : nv - 1;
-                ai[v] = (g0 + v < nv) ? sign * a[ic] : 0.0;
+                const bool live = g0 + v < nv;  // dead slots: one broadcast address, coefficient 0
+                const int ic = live ? g0 + v : 0;
+                ai[v] = live ? sign * a[ic] : 0.0;
                 const double *Vi = V + (size_t)ic * ldv;
 #pragma unroll
-                for (int u = 0; u < U; ++u) t[v][u] = ld2s<NT>(Vi, idx[u]);
+                for (int u = 0; u < U; ++u) t[v][u] = ld2s<NT>(Vi, live ? idx[u] : 0);
             }
 #pragma unroll
             for (int v = 0; v < G; ++v) {
