@@ -130,7 +130,8 @@ def main():
     n, nnz_global = S.grid_sizes(M, My)
     t_setup = time.time()
     rb, re_ = S.partition_slab(M, My, rank, world)
-    A, f = S.AssembleOperator_Laplace(M, My, rb, re_)
+    asm_threads = max(1, min(16, host_cores() // max(1, world)))   # N ranks share the host: stay far below
+    A, f = S.AssembleOperator_Laplace(M, My, rb, re_, nthreads=asm_threads)  # the box's thread limits
     saddle = args.pc != "jacobi"
     B = g = None
     if saddle:
@@ -191,6 +192,7 @@ def main():
             traffic = None
 
     if rank != 0:
+        ctx.vec_destroy(b_dev); ctx.vec_destroy(x_dev); ctx.close()   # RCCL communicator down before torch's
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -266,6 +268,7 @@ def main():
                                "label": "PETSc-equivalent CPU restatement (PETSc not installable offline)"}
         out["speedup_vs_cpu"] = its_per_s / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    ctx.vec_destroy(b_dev); ctx.vec_destroy(x_dev); ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1295,6 +1295,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
     double *__restrict__ z, double *__restrict__ c, KrylovArrays ka, int loc_prev,
     const double *__restrict__ dots_prev, const int32_t *__restrict__ done)
 {
+    // c == nullptr: Jacobi head (K = A, m = 0): v = w'/||w'||, z = D v, nothing pre-loaded
     if (*done) return;
     __shared__ double ys[MP], xs[MP], ts[MP];
     const double tt = sqrt(nrm[0]);
@@ -1351,11 +1352,13 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
             zz.x -= s0;
             zz.y -= s1;
         }
-        cc.x = s0 / d.x;
-        cc.y = s1 / d.y;
         reinterpret_cast<double2 *>(v)[i] = w;
         reinterpret_cast<double2 *>(z)[i] = zz;
-        reinterpret_cast<double2 *>(c)[i] = cc;
+        if (c) {
+            cc.x = s0 / d.x;
+            cc.y = s1 / d.y;
+            reinterpret_cast<double2 *>(c)[i] = cc;
+        }
     }
 }
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,

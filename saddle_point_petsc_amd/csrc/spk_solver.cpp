@@ -455,6 +455,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR;
     const int m = c->m;
     const int32_t nl = c->n_local;
+    // the same head kernel without a constraint block: Jacobi on K = A (the reference as written,
+    // SaddlePointProblem.c:66, and BASELINE config 2): VecScale + PCApply_Jacobi + deferred Givens
+    const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && nl % 2 == 0 && nl > 0;
+    const bool head = fused || fusedj;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
     const double *bdp = fused ? c->bd.p : nullptr;
     // single-reduction Gram-Schmidt (fused CGS without refinement): h = V^T w, q = B D w and w.w
@@ -472,7 +476,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
         k::krylov_cycle_begin(c->ka, nrmbuf(1), s, single ? c->ka.tb : nullptr, m);
-        if (!fused) k::scale_dev(Vj(0), N, inv_tt, done, s);
+        if (!head) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
         int last = -1;  // last iteration of this cycle whose Givens step is still pending (fused path)
@@ -493,6 +497,11 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true);
                 else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true);
                 if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, w, done, s);
+            } else if (fusedj) {
+                k::fused_head(Vj(loc), nrmbuf(loc + 1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER,
+                              nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s);
+                last = loc;
+                op_mult(c, Zj(loc), w, done);            // w = A z_j (halo inside)
             } else {
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
@@ -532,7 +541,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::krylov_refine_merge(c->ka, loc, db, sm2, nb, nrm2b, nn, s);
                 }
             }
-            if (!fused) {
+            if (!head) {
                 // Hessenberg column, Givens, convergence -- on the device; then v_{j+1} = w / ||w||
                 k::krylov_givens(c->ka, loc, db, nb, s);
                 k::scale_dev(w, N, inv_tt, done, s);
@@ -544,7 +553,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             }
         }
         // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
-        if (fused && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
+        if (head && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
         k::krylov_cycle_end(c->ka, s);
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);

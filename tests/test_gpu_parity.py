@@ -157,6 +157,12 @@ def test_fgmres_jacobi_matches_oracle_and_fixture(spk, oracle, golden_m32):
     assert info["its"] == 75 and info["reason"] == 2
     assert np.allclose(info["history"], golden_m32["jacobi_hist"], rtol=1e-6)
     assert relerr(x, xo) < 1e-8
+    # head-kernel path (default) against the step-by-step PCApply / MatMult / VecScale path
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.pc_setup(spk.PC_JACOBI)
+        xu, iu = c.fgmres(f, rtol=1e-5, fused=0)
+    assert iu["its"] == info["its"] and np.allclose(iu["history"], info["history"], rtol=1e-9) and relerr(xu, x) < 1e-10
 
 
 @pytest.mark.parametrize("fact", [0, 1, 2, 3])
