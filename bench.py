@@ -130,12 +130,15 @@ def main():
     n, nnz_global = S.grid_sizes(M, My)
     t_setup = time.time()
     rb, re_ = S.partition_slab(M, My, rank, world)
+    t_asm = time.time()
     asm_threads = max(1, min(16, host_cores() // max(1, world)))   # N ranks share the host: stay far below
     A, f = S.AssembleOperator_Laplace(M, My, rb, re_, nthreads=asm_threads)  # the box's thread limits
     saddle = args.pc != "jacobi"
     B = g = None
     if saddle:
         B, g = S.AssembleOperator_Constraints(M, My, rb, re_)
+    t_asm = time.time() - t_asm
+    t_up = time.time()
     ctx = S.Context(local_rank)
     if use_dist:
         ids = [S.unique_id() if rank == 0 else None]
@@ -147,7 +150,10 @@ def main():
     pc = S.PC_JACOBI if not saddle else S.PC_SCHUR
     fact = {"schur-full": S.SCHUR_FULL, "schur-lower": S.SCHUR_LOWER, "schur-upper": S.SCHUR_UPPER,
             "schur-diag": S.SCHUR_DIAG, "jacobi": S.SCHUR_FULL}[args.pc]
+    t_up = time.time() - t_up
+    t_pc = time.time()
     ctx.pc_setup(pc, fact)
+    t_pc = time.time() - t_pc
     rhs = np.concatenate([f, g]) if saddle else f
     b_dev = ctx.vec_create(rhs)
     x_dev = ctx.vec_create(n=len(rhs))
@@ -224,6 +230,7 @@ def main():
         "spmv_ms": spmv_ms,
         "residual_after_steps": info["rnorm"] / info["rnorm0"] if info["rnorm0"] else None,
         "setup_seconds": t_setup,
+        "setup_breakdown": {"host_assembly": t_asm, "set_operators_upload": t_up, "pc_setup": t_pc},
         # achieved = ALGORITHMIC (CSR) bytes / time.  When the kernel streams the
         # 2x2-blocked layout its true bytes are fewer: both rates are reported and `frac` is the
         # LOWER of the two fractions, as SURVEY 8(d) prescribes for compressed layouts.

@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -139,12 +140,34 @@ Comm *make_local_comm(spk_local_group *grp, int rank);
 // ---------------------------------------------------------------------------
 // host-side partition results
 // ---------------------------------------------------------------------------
+// uninitialised host array (std::vector would zero hundreds of MB on one thread first)
+template <class T>
+struct HostBuf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t count)
+    {
+        p.reset(new T[count ? count : 1]);
+        n = count;
+    }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+// fn(begin, end, thread) over [0, n) on up to `hardware threads` host threads
+void parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int max_threads = 0);
+
 struct SplitCsr {
-    std::vector<int32_t> d_rowptr, d_colidx, o_rowptr, o_colidx, garray;
-    std::vector<double> d_val, o_val;
+    HostBuf<int32_t> d_rowptr, d_colidx, o_rowptr, o_colidx;
+    HostBuf<double> d_val, o_val;
+    std::vector<int32_t> garray;
+    bool bad_column = false;  // a column outside [0, ncols_global)
+    int32_t bad_value = 0;
 };
 void split_csr(int64_t row_begin, int32_t nrows_local, const int32_t *rowptr,
-               const int32_t *colidx, const double *val, SplitCsr &out);
+               const int32_t *colidx, const double *val, SplitCsr &out, int64_t ncols_global = -1);
 
 // ---------------------------------------------------------------------------
 // Krylov state that lives in device memory (one per context)

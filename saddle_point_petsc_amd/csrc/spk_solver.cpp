@@ -56,8 +56,9 @@ namespace spk {
 // ---------------------------------------------------------------------------
 // KSPSetOperators: upload one block (SaddlePointProblem.c:66; the nest at :45-60)
 // ---------------------------------------------------------------------------
-static void upload_csr(CsrDev &D, int32_t nrows, int32_t ncols, const std::vector<int32_t> &rowptr,
-                       const std::vector<int32_t> &colidx, const std::vector<double> &val, bool tiles)
+template <class VR, class VI, class VD>
+static void upload_csr(CsrDev &D, int32_t nrows, int32_t ncols, const VR &rowptr, const VI &colidx, const VD &val,
+                       bool tiles)
 {
     D.nrows = nrows;
     D.ncols = ncols;
@@ -77,47 +78,64 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
                         const int32_t *rowptr, const int32_t *colidx, const double *val)
 {
     if (rowptr[0] != 0) fail(SPK_ERR_ARG, "A00: rowptr[0] must be 0");
-    const int64_t nnz = rowptr[nrows_local];
-    for (int64_t k = 0; k < nnz; ++k)
-        if (colidx[k] < 0 || colidx[k] >= ncols_global)
-            fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", colidx[k], (long long)ncols_global);
     if (row_begin < 0 || row_begin + nrows_local > ncols_global)
         fail(SPK_ERR_ARG, "A00: rows [%lld,%lld) outside the %lld x %lld block", (long long)row_begin,
              (long long)(row_begin + nrows_local), (long long)ncols_global, (long long)ncols_global);
+    for (int32_t r = 0; r < nrows_local; ++r)
+        if (rowptr[r + 1] < rowptr[r]) fail(SPK_ERR_ARG, "A00: rowptr not monotone at row %d", r);
 
     SplitCsr sp;
-    split_csr(row_begin, nrows_local, rowptr, colidx, val, sp);
+    split_csr(row_begin, nrows_local, rowptr, colidx, val, sp, ncols_global);  // threaded, validates the columns
+    if (sp.bad_column) fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", sp.bad_value, (long long)ncols_global);
     c->n_global = ncols_global;
     c->row_begin = row_begin;
     c->n_local = nrows_local;
     c->n_ghost = (int32_t)sp.garray.size();
     upload_csr(c->Ad, nrows_local, nrows_local, sp.d_rowptr, sp.d_colidx, sp.d_val, true);
 
-    // 2x2-blocked copy when every row pair shares its pattern and columns pair up (dof-2 grids)
+    // 2x2-blocked copy when every row pair shares its pattern and columns pair up (dof-2 grids).
+    // Block row br then starts at block rp[2 br] / 4, so one threaded pass verifies and fills.
     {
         BcsrDev &Ab = c->Ab;
         Ab.ok = false;
         Ab.nbrows = 0;
         Ab.ntiles = 0;
-        bool ok = nrows_local % 2 == 0 && nrows_local > 0;
         const auto &rp = sp.d_rowptr;
         const auto &ci = sp.d_colidx;
-        std::vector<int32_t> brp, bcol;
-        std::vector<double> vt, vb;
+        const int64_t nnzd = rp[(size_t)nrows_local];
+        bool ok = nrows_local % 2 == 0 && nrows_local > 0 && nnzd % 4 == 0;
+        HostBuf<int32_t> brp, bcol;
+        HostBuf<double> vt, vb;
         if (ok) {
-            brp.assign(1, 0);
-            for (int32_t r = 0; ok && r < nrows_local; r += 2) {
-                const int32_t k0 = rp[r], k1 = rp[r + 1], l0 = rp[r + 1], l1 = rp[r + 2];
-                if ((k1 - k0) != (l1 - l0) || ((k1 - k0) & 1)) { ok = false; break; }
-                for (int32_t k = 0; k < k1 - k0; k += 2) {
-                    const int32_t c0 = ci[k0 + k], c1 = ci[k0 + k + 1];
-                    if ((c0 & 1) || c1 != c0 + 1 || ci[l0 + k] != c0 || ci[l0 + k + 1] != c1) { ok = false; break; }
-                    bcol.push_back(c0 >> 1);
-                    vt.push_back(sp.d_val[k0 + k]); vt.push_back(sp.d_val[k0 + k + 1]);
-                    vb.push_back(sp.d_val[l0 + k]); vb.push_back(sp.d_val[l0 + k + 1]);
+            const int32_t nbr = nrows_local / 2;
+            brp.alloc((size_t)nbr + 1);
+            bcol.alloc((size_t)(nnzd / 4));
+            vt.alloc((size_t)(nnzd / 2));
+            vb.alloc((size_t)(nnzd / 2));
+            std::vector<int> fail_t(64, 0);
+            parallel_for(nbr, [&](int64_t b0, int64_t b1, int t) {
+                for (int64_t br = b0; br < b1; ++br) {
+                    const int32_t r = (int32_t)(2 * br);
+                    const int32_t k0 = rp[(size_t)r], k1 = rp[(size_t)r + 1], l0 = k1, l1 = rp[(size_t)r + 2];
+                    if ((k1 - k0) != (l1 - l0) || ((k1 - k0) & 1) || (k0 & 3)) { fail_t[(size_t)t] = 1; return; }
+                    brp[(size_t)br] = k0 / 4;
+                    int64_t q = k0 / 4;
+                    for (int32_t k = 0; k < k1 - k0; k += 2, ++q) {
+                        const int32_t c0 = ci[(size_t)(k0 + k)], c1 = ci[(size_t)(k0 + k + 1)];
+                        if ((c0 & 1) || c1 != c0 + 1 || ci[(size_t)(l0 + k)] != c0 || ci[(size_t)(l0 + k + 1)] != c1) {
+                            fail_t[(size_t)t] = 1;
+                            return;
+                        }
+                        bcol[(size_t)q] = c0 >> 1;
+                        vt[(size_t)(2 * q)] = sp.d_val[(size_t)(k0 + k)];
+                        vt[(size_t)(2 * q + 1)] = sp.d_val[(size_t)(k0 + k + 1)];
+                        vb[(size_t)(2 * q)] = sp.d_val[(size_t)(l0 + k)];
+                        vb[(size_t)(2 * q + 1)] = sp.d_val[(size_t)(l0 + k + 1)];
+                    }
                 }
-                brp.push_back((int32_t)bcol.size());
-            }
+            });
+            for (int f : fail_t) ok = ok && !f;
+            if (ok) brp[(size_t)nbr] = (int32_t)(nnzd / 4);
         }
         if (ok) {
             Ab.nbrows = nrows_local / 2;
@@ -139,9 +157,9 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     // compress the off-rank block to the rows that have entries
     std::vector<int32_t> rows, orp(1, 0);
     for (int32_t r = 0; r < nrows_local; ++r)
-        if (sp.o_rowptr[r + 1] > sp.o_rowptr[r]) {
+        if (sp.o_rowptr[(size_t)r + 1] > sp.o_rowptr[(size_t)r]) {
             rows.push_back(r);
-            orp.push_back(sp.o_rowptr[r + 1]);
+            orp.push_back(sp.o_rowptr[(size_t)r + 1]);
         }
     upload_csr(c->Ao, (int32_t)rows.size(), c->n_ghost, orp, sp.o_colidx, sp.o_val, false);
     c->ao_rows.upload(rows.data(), rows.size(), 8);
@@ -206,7 +224,8 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
         const int32_t k0 = rowptr[r], k1 = rowptr[r + 1];
         std::vector<int32_t> perm((size_t)(k1 - k0));
         std::iota(perm.begin(), perm.end(), k0);
-        std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return colidx[a] < colidx[b]; });
+        if (!std::is_sorted(colidx + k0, colidx + k1))  // PETSc rows come sorted: no work then
+            std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return colidx[a] < colidx[b]; });
         for (int32_t i = 0; i < k1 - k0; ++i) {
             const int32_t g = colidx[perm[(size_t)i]];
             if (g < lo || g >= hi) fail(SPK_ERR_ARG, "A10: column %d not owned by this rank [%lld,%lld)", g, (long long)lo, (long long)hi);
