@@ -17,6 +17,11 @@
  *   SpkMatShellCreate(A, B, &K)  MATSHELL whose MatMult is spk_mult.
  *   SpkKSPSolveNative(...)       the whole KSPSolve (FGMRES + PC + MatMult +
  *                                Gram-Schmidt) on the device: spk_fgmres.
+ *   SpkKSPRegister()             the same as a registered KSP type: after one call at
+ *                                start-up, `-ksp_type spk_fgmres` makes the reference's
+ *                                unmodified KSPSolve(ksp, f, u) (SaddlePointProblem.c:70)
+ *                                run on the device.  Operators are taken from
+ *                                KSPGetOperators: a MATNEST {A, B^T; B, 0} or a plain AIJ A.
  *
  * Data extraction follows SURVEY.md section 8(b): MatGetOwnershipRange +
  * MatGetRow on the rank's rows (works for SeqAIJ and MPIAIJ, global columns --
@@ -24,6 +29,7 @@
  * PetscInt must be 32-bit and PetscScalar real double (asserted).
  */
 #include <petscksp.h>
+#include <petsc/private/kspimpl.h> /* KSPRegister'd type: ksp->ops, ksp->data */
 
 #include "spk.h"
 
@@ -312,5 +318,120 @@ PetscErrorCode SpkKSPSolveNative(MPI_Comm comm, Mat A, Mat B, Vec b, Vec x, Pets
     if (its) *its = res.its;
     if (reason) *reason = (KSPConvergedReason)res.reason; /* same numbering */
     ierr = SpkGlueDestroy(g); CHKERRQ(ierr);
+    PetscFunctionReturn(0);
+}
+
+/* ------------------------------------------------- registered KSP type "spk_fgmres" */
+typedef struct {
+    SpkGlue *glue;
+    Mat A, B; /* borrowed from the operator */
+    int schur_fact;
+} KSP_SPK;
+
+static PetscErrorCode KSPSetUp_SPK(KSP ksp)
+{
+    PetscErrorCode ierr;
+    KSP_SPK *d = (KSP_SPK *)ksp->data;
+    Mat Amat, Pmat;
+    PetscBool isnest;
+    MPI_Comm comm;
+
+    PetscFunctionBegin;
+    ierr = PetscObjectGetComm((PetscObject)ksp, &comm); CHKERRQ(ierr);
+    ierr = KSPGetOperators(ksp, &Amat, &Pmat); CHKERRQ(ierr);
+    ierr = PetscObjectTypeCompare((PetscObject)Amat, MATNEST, &isnest); CHKERRQ(ierr);
+    if (isnest) { /* {A, B^T; B, 0}: blocks (0,0) and (1,0) */
+        ierr = MatNestGetSubMat(Amat, 0, 0, &d->A); CHKERRQ(ierr);
+        ierr = MatNestGetSubMat(Amat, 1, 0, &d->B); CHKERRQ(ierr);
+    } else {      /* as written in the reference: KSPSetOperators(ksp, A, A), :66 */
+        d->A = Amat;
+        d->B = NULL;
+    }
+    if (d->glue) { ierr = SpkGlueDestroy(d->glue); CHKERRQ(ierr); d->glue = NULL; }
+    ierr = SpkGlueCreate(comm, d->A, d->B, &d->glue); CHKERRQ(ierr);
+    SPK_CHK(d->glue->ctx, spk_pc_setup(d->glue->ctx, d->B ? SPK_PC_SCHUR : SPK_PC_JACOBI, d->schur_fact));
+    PetscFunctionReturn(0);
+}
+
+static PetscErrorCode KSPSolve_SPK(KSP ksp)
+{
+    PetscErrorCode ierr;
+    KSP_SPK *d = (KSP_SPK *)ksp->data;
+    spk_opts o;
+    spk_result res;
+
+    PetscFunctionBegin;
+    spk_default_opts(&o);
+    o.rtol = ksp->rtol;          /* -ksp_rtol   */
+    o.abstol = ksp->abstol;      /* -ksp_atol   */
+    o.dtol = ksp->divtol;        /* -ksp_divtol */
+    o.max_it = ksp->max_it;      /* -ksp_max_it */
+    o.guess_nonzero = ksp->guess_zero ? 0 : 1;
+    ierr = PetscOptionsGetInt(((PetscObject)ksp)->options, ((PetscObject)ksp)->prefix, "-ksp_gmres_restart", &o.restart, NULL); CHKERRQ(ierr);
+    ierr = SpkGather(d->glue, ksp->vec_rhs, d->glue->xbuf); CHKERRQ(ierr);
+    if (o.guess_nonzero) { ierr = SpkGather(d->glue, ksp->vec_sol, d->glue->ybuf); CHKERRQ(ierr); }
+    SPK_CHK(d->glue->ctx, spk_fgmres(d->glue->ctx, d->glue->xbuf, d->glue->ybuf, SPK_MEM_HOST, &o, &res, NULL, 0));
+    ierr = SpkScatter(d->glue, d->glue->ybuf, ksp->vec_sol); CHKERRQ(ierr);
+    ksp->its = res.its;
+    ksp->rnorm = res.rnorm;
+    ksp->reason = (KSPConvergedReason)res.reason; /* same numbering as KSPConvergedReason */
+    PetscFunctionReturn(0);
+}
+
+static PetscErrorCode KSPSetFromOptions_SPK(PetscOptionItems *PetscOptionsObject, KSP ksp)
+{
+    PetscErrorCode ierr;
+    KSP_SPK *d = (KSP_SPK *)ksp->data;
+    char fact[32] = "full";
+    PetscBool set;
+
+    PetscFunctionBegin;
+    (void)PetscOptionsObject;
+    ierr = PetscOptionsGetString(((PetscObject)ksp)->options, ((PetscObject)ksp)->prefix, "-pc_fieldsplit_schur_fact_type", fact, sizeof fact, &set); CHKERRQ(ierr);
+    if (set) {
+        if (!strcmp(fact, "diag")) d->schur_fact = SPK_SCHUR_DIAG;
+        else if (!strcmp(fact, "lower")) d->schur_fact = SPK_SCHUR_LOWER;
+        else if (!strcmp(fact, "upper")) d->schur_fact = SPK_SCHUR_UPPER;
+        else d->schur_fact = SPK_SCHUR_FULL;
+    }
+    PetscFunctionReturn(0);
+}
+
+static PetscErrorCode KSPDestroy_SPK(KSP ksp)
+{
+    PetscErrorCode ierr;
+    KSP_SPK *d = (KSP_SPK *)ksp->data;
+    PetscFunctionBegin;
+    if (d->glue) { ierr = SpkGlueDestroy(d->glue); CHKERRQ(ierr); }
+    ierr = PetscFree(ksp->data); CHKERRQ(ierr);
+    PetscFunctionReturn(0);
+}
+
+static PetscErrorCode KSPCreate_SPK(KSP ksp)
+{
+    PetscErrorCode ierr;
+    KSP_SPK *d;
+    PetscFunctionBegin;
+    ierr = PetscNew(&d); CHKERRQ(ierr);
+    d->schur_fact = SPK_SCHUR_FULL; /* PETSc's default -pc_fieldsplit_schur_fact_type */
+    ksp->data = (void *)d;
+    ierr = KSPSetSupportedNorm(ksp, KSP_NORM_UNPRECONDITIONED, PC_RIGHT, 3); CHKERRQ(ierr); /* FGMRES: right PC */
+    ksp->ops->setup = KSPSetUp_SPK;
+    ksp->ops->solve = KSPSolve_SPK;
+    ksp->ops->destroy = KSPDestroy_SPK;
+    ksp->ops->setfromoptions = KSPSetFromOptions_SPK;
+    ksp->ops->view = NULL;
+    ksp->ops->buildsolution = KSPBuildSolutionDefault;
+    ksp->ops->buildresidual = KSPBuildResidualDefault;
+    PetscFunctionReturn(0);
+}
+
+/* Call once after PetscInitialize (main.c:12); then the reference's call site works
+ * unchanged with  -ksp_type spk_fgmres [-pc_fieldsplit_schur_fact_type full] ... */
+PetscErrorCode SpkKSPRegister(void)
+{
+    PetscErrorCode ierr;
+    PetscFunctionBegin;
+    ierr = KSPRegister("spk_fgmres", KSPCreate_SPK); CHKERRQ(ierr);
     PetscFunctionReturn(0);
 }
