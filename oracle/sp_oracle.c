@@ -648,6 +648,8 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
                 }
             }
             tt = spo_vec_norm(N, VV(loc + 1));
+            /* KSPCheckNorm: a NaN/Inf norm ends the solve with KSP_DIVERGED_NANORINF */
+            if (isnan(tt) || isinf(tt)) { reason = SPO_DIVERGED_NANORINF; rnorm = tt; break; }
             /* happy breakdown test */
             hapbnd = fabs(tt / rs[loc]);
             if (hapbnd > haptol) hapbnd = haptol;

@@ -1221,6 +1221,12 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
     __syncthreads();
     if (threadIdx.x != 0) return;
     const double tt = sqrt(*nrm2);
+    if (isnan(tt) || isinf(tt)) {  // KSPCheckNorm: KSP_DIVERGED_NANORINF
+        st->rnorm = tt;
+        st->reason = SPK_DIVERGED_NANORINF;
+        st->done = 1;
+        return;
+    }
     // happy breakdown test
     double hapbnd = fabs(tt / ka.rs[loc]);
     if (hapbnd > 1e-30) hapbnd = 1e-30;

@@ -294,6 +294,36 @@ def test_fgmres_edge_cases(spk, oracle):
         assert info["reason"] == -9
 
 
+def test_fgmres_invariant_subspace_and_bad_data(spk, oracle):
+    """K = 2 I: the Krylov space is invariant after one step (w' vanishes, PETSc's happy-breakdown
+    corner); NaN inside the operator; a singular (zero) operator."""
+    n = 8
+    A = spk.CSR(np.arange(n + 1), np.arange(n), 2 * np.ones(n), n)
+    b = np.arange(1, n + 1, dtype=float)
+    for pc in (spk.PC_NONE, spk.PC_JACOBI):
+        with spk.Context(0) as c:
+            c.set_block(spk.BLOCK_A00, A)
+            c.pc_setup(pc)
+            x, info = c.fgmres(b, rtol=1e-12)
+        xo, io = oracle.fgmres(oracle.CSR(A.rowptr, A.colidx, A.val, n), b, pc_type=pc, rtol=1e-12)
+        assert info["its"] == io["its"] == 1 and info["reason"] == io["reason"] == 2
+        assert np.allclose(x, b / 2, rtol=1e-14)
+    An = spk.CSR(A.rowptr, A.colidx, np.where(np.arange(n) == 3, np.nan, 2.0), n)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, An)
+        c.pc_setup(spk.PC_NONE)
+        _, info = c.fgmres(b)
+    assert info["reason"] == -9                                          # KSP_DIVERGED_NANORINF
+    Az = spk.CSR(A.rowptr, A.colidx, np.zeros(n), n)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, Az)
+        c.pc_setup(spk.PC_JACOBI)                                        # zero diagonal -> 1 (PCJACOBI)
+        assert np.array_equal(c.jacobi_diag(), np.ones(n))
+        _, info = c.fgmres(b, max_it=5)
+    _, io = oracle.fgmres(oracle.CSR(Az.rowptr, Az.colidx, Az.val, n), b, pc_type=oracle.PC_JACOBI, max_it=5)
+    assert info["reason"] == io["reason"] and info["reason"] < 0 and info["its"] == io["its"]
+
+
 def test_fgmres_config3_512_truncated(spk, oracle):
     """BASELINE config 3 (512 x 512, full Schur path): 45 iterations of both
     implementations must agree (the oracle finishes this in seconds)."""
