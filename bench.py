@@ -189,6 +189,8 @@ def main():
     achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9
     spi = ctx.spmv_info()
     achieved_layout = spi["layout_bytes"] / (spmv_ms * 1e-3) / 1e9
+    # the variant the fused Schur iteration launches: y += A x (y pre-loaded with B^T lambda): 8n more bytes
+    acc_ms = ctx.time_kernel("spmv_acc", 0, 20, args.spmv_reps)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if os.path.exists(tpath) and world == 1 and M == 1024 and My == 1024:
@@ -242,7 +244,9 @@ def main():
                      "frac_algorithmic_csr_bytes": achieved / HBM_PEAK_GBS,
                      "achieved_layout_bytes": achieved_layout, "layout_bytes_per_launch": spi["layout_bytes"],
                      "frac_of_measured_copy": min(achieved, achieved_layout) / HBM_COPY_GBS,
-                     "bytes_per_launch": alg_bytes, "traffic": traffic},
+                     "bytes_per_launch": alg_bytes, "traffic": traffic,
+                     "in_solver_variant": {"kernel": "y += A x (fused Schur path)", "ms": acc_ms,
+                                           "layout_gbps": (spi["layout_bytes"] + 8 * sz["n_local"]) / (acc_ms * 1e-3) / 1e9}},
     }
     if it_bytes:
         out["iteration_model"] = {"bytes_per_iteration": it_bytes,

@@ -384,6 +384,10 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
     auto run = [&]() {
         if (w == "spmv") spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s);
         else if (w == "spmv_bcsr") { if (!c->Ab.ok) spk::fail(SPK_ERR_STATE, "no 2x2-blocked copy"); spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s); }
+        else if (w == "spmv_acc") {  // y += A x in the active format: the variant the fused Schur path launches
+            if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s, true);
+            else spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s, true);
+        }
         else if (w == "mult") spk::op_mult(c, x, y, nullptr);
         else if (w == "pc") { if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "pc not set up"); spk::op_pc_apply(c, x, y, nullptr); }
         else if (w == "mdot") spk::k::mdot(V.p, ld, nv, x, N, N, c->fin(c->small.p), nullptr, s);

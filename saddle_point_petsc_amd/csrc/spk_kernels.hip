@@ -281,14 +281,16 @@ void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &
     }
 }
 
-template <bool NT>
+// ACC: y += A x (the fused Schur path pre-loads y with B^T lambda); a separate instantiation so
+// that profiles list the plain product (the one bench.py times for the roofline) on its own line
+template <bool NT, bool ACC>
 __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
     const double *__restrict__ vtop, const double *__restrict__ vbot,
     const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ bt_rowptr,
     const int32_t *__restrict__ bt_colidx, const double *__restrict__ bt_val,
-    const double *__restrict__ lam, int accumulate, const int32_t *__restrict__ done)
+    const double *__restrict__ lam, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
             double o = ((red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + red[4 * threadIdx.x + 2]) + red[4 * threadIdx.x + 3];
             if (bt_rowptr)
                 for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) o += bt_val[k] * lam[bt_colidx[k]];
-            if (accumulate) o += y[r];
+            if (ACC) o += y[r];
             y[r] = o;
         }
         return;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
         const int r = 2 * br0 + lr;
         if (bt_rowptr)
             for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
-        if (accumulate) s += y[r];
+        if (ACC) s += y[r];
         y[r] = s;
     }
 }
@@ -377,9 +379,14 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
     if (A.nbrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
     // non-temporal loads on the matrix planes (read once per SpMV): 70.7 -> 61.3 us in the same run
-    hipLaunchKernelGGL((spmv_bcsr_kernel<true>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, A.vtop.p,
-                       A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done);
+    if (accumulate)
+        hipLaunchKernelGGL((spmv_bcsr_kernel<true, true>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p,
+                           A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, done);
+    else
+        hipLaunchKernelGGL((spmv_bcsr_kernel<true, false>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p,
+                           A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, done);
 }
 
 // compressed off-rank block: few short rows, one thread per row
