@@ -120,8 +120,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SPK_BENCH_COMM") == "gloo":
+            # rehearsal on a 1-GPU box: N processes share GPU 0 (RCCL/NCCL refuse that), collectives
+            # go through the host over gloo.  Exercises the multi-process flow, not its speed.
+            dist.init_process_group("gloo")
+            local_rank = 0
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import saddle_point_petsc_amd as S   # fails loudly if libspk.so is not built
 
@@ -140,7 +146,9 @@ def main():
     t_asm = time.time() - t_asm
     t_up = time.time()
     ctx = S.Context(local_rank)
-    if use_dist:
+    if use_dist and os.environ.get("SPK_BENCH_COMM") == "gloo":
+        ctx.comm_init_torch(dist, rank, world)
+    elif use_dist:
         ids = [S.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init_rccl(rank, world, ids[0])
@@ -162,7 +170,8 @@ def main():
     def barrier():
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if dist.get_backend() == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300, single_reduce=args.single_reduce)
@@ -178,7 +187,7 @@ def main():
     assert info["its"] == args.steps, info
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

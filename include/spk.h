@@ -120,6 +120,19 @@ void spk_default_opts(spk_opts *opts);
  * bench.py), every rank calls spk_comm_init_rccl before spk_set_block. */
 int spk_comm_unique_id(void *id128);
 int spk_comm_init_rccl(spk_ctx *ctx, int rank, int nranks, const void *id128);
+/* Host-callback transport (rehearsal only: lets N processes share ONE GPU, which RCCL
+ * refuses, so that the multi-process flow of bench.py can be run on a 1-GPU box over
+ * gloo/MPI).  Every collective is staged through the host and synchronises the stream.
+ *   allreduce(user, buf, count): in-place sum over ranks of `count` doubles
+ *   exchange(user, peer, send, nsend, recv, nrecv): one matched send/recv pair of doubles
+ *   allgather(user, in, out, bytes_each): bytes from every rank, rank order */
+typedef struct spk_host_comm {
+    void *user;
+    int (*allreduce)(void *user, double *buf, int count);
+    int (*exchange)(void *user, int peer, const double *send, int64_t nsend, double *recv, int64_t nrecv);
+    int (*allgather)(void *user, const void *in, void *out, int64_t bytes_each);
+} spk_host_comm;
+int spk_comm_init_host(spk_ctx *ctx, int rank, int nranks, const spk_host_comm *cb);
 /* In-process logical ranks on one device (parity tests of the partitioned
  * algorithm on a 1-GPU box): a group is shared by `nranks` contexts, each
  * driven by its own host thread. */

@@ -40,6 +40,16 @@ class Result(C.Structure):
     ]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int64)
+ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class HostComm(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allreduce", ALLREDUCE_CB), ("exchange", EXCHANGE_CB),
+                ("allgather", ALLGATHER_CB)]
+
+
 class MatCSR(C.Structure):
     _fields_ = [
         ("row_begin", C.c_int64), ("nrows_local", C.c_int32), ("pad", C.c_int32),
@@ -64,6 +74,7 @@ def _load():
     L.spk_destroy.argtypes = [vp]
     L.spk_comm_unique_id.argtypes = [C.c_char_p]
     L.spk_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.spk_comm_init_host.argtypes = [vp, C.c_int, C.c_int, C.POINTER(HostComm)]
     L.spk_local_group_create.argtypes = [C.POINTER(vp), C.c_int]
     L.spk_local_group_destroy.argtypes = [vp]
     L.spk_comm_init_local.argtypes = [vp, vp, C.c_int]

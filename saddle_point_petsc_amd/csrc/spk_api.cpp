@@ -125,6 +125,16 @@ int spk_comm_init_rccl(spk_ctx *c, int rank, int nranks, const void *id128)
     SPK_CATCH(c)
 }
 
+int spk_comm_init_host(spk_ctx *c, int rank, int nranks, const spk_host_comm *cb)
+{
+    SPK_TRY(c)
+    if (!cb || !cb->allreduce || !cb->exchange || !cb->allgather || nranks < 1 || rank < 0 || rank >= nranks)
+        spk::fail(SPK_ERR_ARG, "comm_init_host: bad arguments");
+    if (c->have_A) spk::fail(SPK_ERR_STATE, "comm_init: must precede spk_set_block");
+    c->comm.reset(spk::make_host_comm(rank, nranks, *cb));
+    SPK_CATCH(c)
+}
+
 int spk_comm_init_local(spk_ctx *c, spk_local_group *grp, int rank)
 {
     SPK_TRY(c)

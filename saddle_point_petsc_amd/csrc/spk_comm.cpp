@@ -253,8 +253,64 @@ private:
     int rank_;
 };
 
+// Host-callback transport: every operation goes device -> host -> callback -> device.
+class HostCbComm : public Comm {
+public:
+    HostCbComm(int rank, int nranks, const spk_host_comm &cb) : rank_(rank), n_(nranks), cb_(cb) {}
+    int rank() const override { return rank_; }
+    int size() const override { return n_; }
+    void allreduce_sum(double *dev, int count, hipStream_t s) override
+    {
+        if (count <= 0) return;
+        std::vector<double> h((size_t)count);
+        SPK_HIP(hipMemcpyAsync(h.data(), dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        if (cb_.allreduce(cb_.user, h.data(), count)) fail(SPK_ERR_COMM, "host all-reduce callback failed");
+        SPK_HIP(hipMemcpyAsync(dev, h.data(), sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s));
+        SPK_HIP(hipStreamSynchronize(s));
+    }
+    void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
+                  double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override
+    {
+        if (peers.empty()) return;
+        const int64_t ns = send_off.back(), nr = recv_off.back();
+        std::vector<double> hs((size_t)std::max<int64_t>(ns, 1)), hr((size_t)std::max<int64_t>(nr, 1));
+        if (ns) SPK_HIP(hipMemcpyAsync(hs.data(), sendbuf, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < peers.size(); ++i)
+            if (cb_.exchange(cb_.user, peers[i], hs.data() + send_off[i], send_off[i + 1] - send_off[i],
+                             hr.data() + recv_off[i], recv_off[i + 1] - recv_off[i]))
+                fail(SPK_ERR_COMM, "host exchange callback failed");
+        if (nr) SPK_HIP(hipMemcpyAsync(recvbuf, hr.data(), sizeof(double) * (size_t)nr, hipMemcpyHostToDevice, s));
+        SPK_HIP(hipStreamSynchronize(s));
+    }
+    void host_allgather(const void *in, void *out, size_t bytes_each) override
+    {
+        if (cb_.allgather(cb_.user, in, out, (int64_t)bytes_each)) fail(SPK_ERR_COMM, "host all-gather callback failed");
+    }
+    void host_allgatherv(const void *in, size_t bytes_in, std::vector<std::vector<char>> &out) override
+    {
+        std::vector<int64_t> sizes((size_t)n_);
+        const int64_t mine = (int64_t)bytes_in;
+        host_allgather(&mine, sizes.data(), sizeof(int64_t));
+        int64_t mx = 16;
+        for (auto v : sizes) mx = std::max(mx, v);
+        std::vector<char> padded((size_t)mx, 0), all((size_t)mx * (size_t)n_);
+        if (bytes_in) std::memcpy(padded.data(), in, bytes_in);
+        host_allgather(padded.data(), all.data(), (size_t)mx);
+        out.resize((size_t)n_);
+        for (int r = 0; r < n_; ++r)
+            out[(size_t)r].assign(all.begin() + (size_t)mx * r, all.begin() + (size_t)mx * r + (size_t)sizes[(size_t)r]);
+    }
+
+private:
+    int rank_, n_;
+    spk_host_comm cb_;
+};
+
 }  // namespace
 
+Comm *make_host_comm(int rank, int nranks, const spk_host_comm &cb) { return new HostCbComm(rank, nranks, cb); }
 Comm *make_self_comm() { return new SelfComm(); }
 Comm *make_rccl_comm(int rank, int nranks, const void *id128, int device)
 {

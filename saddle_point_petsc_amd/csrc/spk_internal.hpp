@@ -136,6 +136,7 @@ protected:
 Comm *make_self_comm();
 Comm *make_rccl_comm(int rank, int nranks, const void *id128, int device);
 Comm *make_local_comm(spk_local_group *grp, int rank);
+Comm *make_host_comm(int rank, int nranks, const spk_host_comm &cb);
 
 // ---------------------------------------------------------------------------
 // host-side partition results

@@ -74,6 +74,43 @@ class Context:
     def comm_init_rccl(self, rank, nranks, id128):
         self._chk(lib.spk_comm_init_rccl(self.h, rank, nranks, id128))
 
+    def comm_init_torch(self, dist, rank, nranks):
+        """Rehearsal transport over an initialised torch.distributed group (gloo): lets several
+        processes share one GPU, which RCCL refuses.  Slow: every collective goes through the host."""
+        import torch
+        from ._lib import HostComm, ALLREDUCE_CB, EXCHANGE_CB, ALLGATHER_CB
+
+        def allreduce(_u, buf, count):
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t)
+            a[:] = t.numpy()
+            return 0
+
+        def exchange(_u, peer, send, nsend, recv, nrecv):
+            reqs = []
+            if nsend:
+                reqs.append(dist.isend(torch.from_numpy(np.ctypeslib.as_array(send, shape=(nsend,)).copy()), peer))
+            rt = torch.zeros(max(nrecv, 1), dtype=torch.float64)
+            if nrecv:
+                reqs.append(dist.irecv(rt[:nrecv], peer))
+            for r in reqs:
+                r.wait()
+            if nrecv:
+                np.ctypeslib.as_array(recv, shape=(nrecv,))[:] = rt[:nrecv].numpy()
+            return 0
+
+        def allgather(_u, inp, out, nbytes):
+            mine = torch.frombuffer(bytearray(C.string_at(inp, nbytes)), dtype=torch.uint8)
+            parts = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(nranks)]
+            dist.all_gather(parts, mine)
+            C.memmove(out, b"".join(bytes(p.numpy().tobytes()) for p in parts), nbytes * nranks)
+            return 0
+
+        self._cbs = (ALLREDUCE_CB(allreduce), EXCHANGE_CB(exchange), ALLGATHER_CB(allgather))   # keep alive
+        self._hc = HostComm(None, *self._cbs)
+        self._chk(lib.spk_comm_init_host(self.h, rank, nranks, C.byref(self._hc)))
+
     def comm_init_local(self, group, rank):
         self._chk(lib.spk_comm_init_local(self.h, group.h, rank))
 

@@ -563,3 +563,29 @@ def test_rccl_single_rank_communicator(spk, oracle):
         x, info = c.fgmres(rhs, rtol=1e-10)
     xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10)
     assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 1 and relerr(x, xo) < 1e-8
+
+
+def test_bench_multi_process_flow_over_gloo(spk):
+    """bench.py's N > 1 flow (one process per rank, slabs, halo plan exchanged between processes,
+    rank-0 JSON line) with 2 processes sharing this GPU.  RCCL refuses two ranks on one device, so
+    the collectives go through the host-callback transport over gloo (SPK_BENCH_COMM=gloo); the
+    partitioned result must match the single-process one."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--grid", "192", "--steps", "45", "--warmup", "5", "--no-cpu-baseline", "--spmv-reps", "5"]
+
+    def last_json(out):
+        return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                         timeout=240, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, SPK_BENCH_COMM="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"),
+                          "--gpus", "2"] + common, capture_output=True, text=True, timeout=280, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d1, d2 = last_json(one.stdout), last_json(two.stdout)
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["steps"] == 45 and d2["scaling"] == "strong"
+    assert d2["residual_after_steps"] == pytest.approx(d1["residual_after_steps"], rel=1e-6)
+    assert d2["roofline"]["bytes_per_launch"] < d1["roofline"]["bytes_per_launch"]        # half the rows per rank
