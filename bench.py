@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--cpu-its", type=int, default=30)
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound on the CPU baseline sample")
     ap.add_argument("--spmv-reps", type=int, default=200)
+    ap.add_argument("--inner-sweeps", type=int, default=0, help="FP32 damped-Jacobi Richardson sweeps standing for "
+                                                                "diag(A)^-1 in the PC (BASELINE config 5's mixed FP32 inner solve)")
+    ap.add_argument("--inner-omega", type=float, default=0.8)
     ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
     args = ap.parse_args()
 
@@ -160,7 +163,7 @@ def main():
             "schur-diag": S.SCHUR_DIAG, "jacobi": S.SCHUR_FULL}[args.pc]
     t_up = time.time() - t_up
     t_pc = time.time()
-    ctx.pc_setup(pc, fact)
+    ctx.pc_setup(pc, fact, inner_sweeps=args.inner_sweeps, inner_omega=args.inner_omega)
     t_pc = time.time() - t_pc
     rhs = np.concatenate([f, g]) if saddle else f
     b_dev = ctx.vec_create(rhs)
@@ -216,7 +219,8 @@ def main():
 
     its_per_s = args.steps / elapsed
     nnzB_local = B.nnz if saddle else 0
-    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart) if saddle else None
+    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart) \
+        if (saddle and args.inner_sweeps == 0) else None
     out = {
         "metric": METRIC,
         "value": its_per_s,
@@ -234,6 +238,7 @@ def main():
                                + ("saddle K=[A B^T;B 0] with 4 constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (4 if saddle else 0), "pc": args.pc, "restart": args.restart,
+                   "inner_fp32_sweeps": args.inner_sweeps,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},

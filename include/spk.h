@@ -157,6 +157,15 @@ int spk_set_block(spk_ctx *ctx, int which, int64_t row_begin, int32_t nrows_loca
 /* ---- preconditioner (KSPSetUp, SaddlePointProblem.c:68) ------------------ */
 /* Builds diag(A)^-1 and, for SPK_PC_SCHUR, S^ = diag(B diag(A)^-1 B^T). */
 int spk_pc_setup(spk_ctx *ctx, int pc_type, int schur_fact);
+/* Inner solve standing for A^-1 inside the preconditioner (BASELINE config 5: "mixed FP32
+ * inner solve"; PETSc: -fieldsplit_0_ksp_type richardson -fieldsplit_0_ksp_max_it k
+ * -fieldsplit_0_ksp_richardson_scale omega -fieldsplit_0_pc_type jacobi): `sweeps` damped-Jacobi
+ * Richardson sweeps on A in SINGLE precision,
+ *     y_1 = omega D^-1 x ;  y_{s+1} = y_s + omega D^-1 (x - A y_s),
+ * input and result converted from / to FP64 (the outer FGMRES is flexible, so an inexact,
+ * lower-precision A^-1 is legitimate).  sweeps = 0 (default) keeps the plain diag(A)^-1.
+ * Call before spk_pc_setup. */
+int spk_pc_set_inner(spk_ctx *ctx, int sweeps, double omega);
 /* Copies S^ (m doubles) to the host, for inspection. */
 int spk_get_schur_diag(spk_ctx *ctx, double *shat);
 int spk_get_jacobi_diag(spk_ctx *ctx, double *dinv /* n_local */);

@@ -41,6 +41,7 @@ class Options(C.Structure):
         ("max_it", C.c_int32), ("rtol", C.c_double), ("abstol", C.c_double),
         ("dtol", C.c_double), ("guess_nonzero", C.c_int32), ("threads", C.c_int32),
         ("orthog", C.c_int32), ("refine", C.c_int32),
+        ("inner_its", C.c_int32), ("pad1", C.c_int32), ("inner_omega", C.c_double),
     ]
 
 
@@ -72,6 +73,7 @@ def lib():
         L.spo_spmv.argtypes = [C.c_int32, _i32p, _i32p, _f64p, _f64p, _f64p]
         L.spo_apply_K.argtypes = [C.POINTER(Operator), _f64p, _f64p]
         L.spo_pc_apply_once.argtypes = [C.POINTER(Operator), C.c_int, C.c_int, _f64p, _f64p]
+        L.spo_pc_apply_inner.argtypes = [C.POINTER(Operator), C.c_int, C.c_int, C.c_int, C.c_double, _f64p, _f64p]
         L.spo_fgmres.argtypes = [C.POINTER(Operator), C.POINTER(Options), _f64p, _f64p,
                                  C.POINTER(Result), _f64p, C.c_int32]
         L.spo_vec_dot.restype = C.c_double
@@ -183,6 +185,15 @@ def pc_apply(A, B, pc_type, schur_fact, x):
     return y
 
 
+def pc_apply_inner(A, B, pc_type, schur_fact, inner_its, inner_omega, x):
+    """PC with the FP32 Richardson/Jacobi inner solve standing for A^-1."""
+    op = _operator(A, B)
+    y = np.zeros(A.nrows + (B.nrows if B is not None else 0))
+    lib().spo_pc_apply_inner(C.byref(op), pc_type, schur_fact, inner_its, inner_omega,
+                             np.ascontiguousarray(x, np.float64), y)
+    return y
+
+
 def jacobi_dinv(A):
     op = _operator(A, None)
     d = np.zeros(A.nrows)
@@ -200,7 +211,8 @@ def schur_setup(A, B):
 
 
 def fgmres(A, b, B=None, x0=None, pc_type=PC_JACOBI, schur_fact=SCHUR_FULL, restart=30,
-           max_it=10000, rtol=1e-5, abstol=1e-50, dtol=1e4, threads=1, orthog=0, refine=0):
+           max_it=10000, rtol=1e-5, abstol=1e-50, dtol=1e4, threads=1, orthog=0, refine=0,
+           inner_its=0, inner_omega=1.0):
     """PETSc-semantics FGMRES on K = A or [A B^T; B 0].  Returns (x, info)."""
     op = _operator(A, B)
     N = A.nrows + (B.nrows if B is not None else 0)
@@ -208,7 +220,7 @@ def fgmres(A, b, B=None, x0=None, pc_type=PC_JACOBI, schur_fact=SCHUR_FULL, rest
     assert b.shape == (N,)
     x = np.zeros(N) if x0 is None else np.array(x0, np.float64)
     opt = Options(pc_type, schur_fact, restart, max_it, rtol, abstol, dtol,
-                  0 if x0 is None else 1, threads, orthog, refine)
+                  0 if x0 is None else 1, threads, orthog, refine, inner_its, 0, inner_omega)
     res = Result()
     hist = np.zeros(max_it + 2)
     lib().spo_fgmres(C.byref(op), C.byref(opt), b, x, C.byref(res), hist, len(hist))

@@ -418,6 +418,13 @@ typedef struct {
     int32_t guess_nonzero, threads;
     int32_t orthog;  /* 0 classical (PETSc default), 1 modified Gram-Schmidt */
     int32_t refine;  /* CGS refinement: 0 never (default), 1 ifneeded, 2 always */
+    /* inner solve standing for A^-1 in the preconditioner (BASELINE config 5: "mixed FP32 inner
+     * solve"): inner_its damped-Jacobi Richardson sweeps in SINGLE precision,
+     *   y_1 = omega D^-1 x ; y_{s+1} = y_s + omega D^-1 (x - A y_s)
+     * (PETSc: -fieldsplit_0_ksp_type richardson -fieldsplit_0_ksp_max_it k
+     *  -fieldsplit_0_ksp_richardson_scale omega -fieldsplit_0_pc_type jacobi).  0 = plain D^-1. */
+    int32_t inner_its, pad1;
+    double inner_omega;
 } spo_options;
 
 typedef struct {
@@ -472,7 +479,44 @@ typedef struct {
     const spo_operator *op;
     int pc_type, schur_fact;
     double *dinv, *shat, *t0;
+    int inner_its;
+    double inner_omega;
+    float *a32, *d32, *x32, *y32, *z32;
 } spo_pc;
+
+/* y = A^ ^-1 x : diag(A)^-1 (inner_its == 0) or the FP32 Richardson sweeps above.  All inner
+ * arithmetic is float: products rounded once, sums in CSR order, no contraction. */
+static void spo_inner_apply(const spo_pc *pc, const double *x, double *y)
+{
+    const spo_operator *op = pc->op;
+    const int32_t n = op->n;
+    if (pc->inner_its <= 0) {
+        for (int32_t i = 0; i < n; ++i) y[i] = x[i] * pc->dinv[i];
+        return;
+    }
+    const float om = (float)pc->inner_omega;
+    float *xs = pc->x32, *ya = pc->y32, *yb = pc->z32;
+    for (int32_t i = 0; i < n; ++i) {
+        xs[i] = (float)x[i];
+        const float od = om * pc->d32[i];
+        ya[i] = od * xs[i];
+    }
+    for (int s = 1; s < pc->inner_its; ++s) {
+        for (int32_t i = 0; i < n; ++i) {
+            float r = 0.0f;
+            for (int32_t k = op->a_rowptr[i]; k < op->a_rowptr[i + 1]; ++k) {
+                const float p = pc->a32[k] * ya[op->a_colidx[k]];
+                r += p;
+            }
+            const float od = om * pc->d32[i];
+            const float df = xs[i] - r;
+            const float up = od * df;
+            yb[i] = ya[i] + up;
+        }
+        float *t = ya; ya = yb; yb = t;
+    }
+    for (int32_t i = 0; i < n; ++i) y[i] = (double)ya[i];
+}
 
 /* z = M^-1 v.  Jacobi: PCApply_Jacobi.  Schur: PCApply_FieldSplit_Schur with
  * A^ ^-1 = diag(A)^-1 and S~ = -S^ ; DIAG flips the sign of the Schur block
@@ -487,7 +531,7 @@ void spo_pc_apply(const spo_pc *pc, const double *x, double *y)
     const int32_t n = op->n, m = op->m;
     if (pc->pc_type == SPO_PC_NONE) { spo_copy((int64_t)n + m, x, y); return; }
     if (pc->pc_type == SPO_PC_JACOBI) {
-        for (int32_t i = 0; i < n; ++i) y[i] = x[i] * pc->dinv[i];
+        spo_inner_apply(pc, x, y);
         for (int32_t i = 0; i < m; ++i) y[n + i] = x[n + i]; /* zero diagonal -> 1 */
         return;
     }
@@ -497,11 +541,11 @@ void spo_pc_apply(const spo_pc *pc, const double *x, double *y)
     double t[16];
     switch (pc->schur_fact) {
     case SPO_SCHUR_DIAG:
-        for (int32_t i = 0; i < n; ++i) y0[i] = x0[i] * pc->dinv[i];
+        spo_inner_apply(pc, x0, y0);
         for (int32_t r = 0; r < m; ++r) y1[r] = x1[r] / pc->shat[r];
         break;
     case SPO_SCHUR_LOWER:
-        for (int32_t i = 0; i < n; ++i) y0[i] = x0[i] * pc->dinv[i];
+        spo_inner_apply(pc, x0, y0);
         spo_spmv(m, op->b_rowptr, op->b_colidx, op->b_val, y0, t);
         for (int32_t r = 0; r < m; ++r) y1[r] = -(x1[r] - t[r]) / pc->shat[r];
         break;
@@ -509,31 +553,79 @@ void spo_pc_apply(const spo_pc *pc, const double *x, double *y)
         for (int32_t r = 0; r < m; ++r) y1[r] = -x1[r] / pc->shat[r];
         memset(pc->t0, 0, sizeof(double) * (size_t)n);
         spo_spmv_t_add(m, op->b_rowptr, op->b_colidx, op->b_val, y1, pc->t0);
-        for (int32_t i = 0; i < n; ++i) y0[i] = (x0[i] - pc->t0[i]) * pc->dinv[i];
+        if (pc->inner_its > 0) {
+            for (int32_t i = 0; i < n; ++i) pc->t0[i] = x0[i] - pc->t0[i];
+            spo_inner_apply(pc, pc->t0, y0);
+        } else {
+            for (int32_t i = 0; i < n; ++i) y0[i] = (x0[i] - pc->t0[i]) * pc->dinv[i];
+        }
         break;
     default: /* FULL */
-        for (int32_t i = 0; i < n; ++i) y0[i] = x0[i] * pc->dinv[i];
+        spo_inner_apply(pc, x0, y0);
         spo_spmv(m, op->b_rowptr, op->b_colidx, op->b_val, y0, t);
         for (int32_t r = 0; r < m; ++r) y1[r] = -(x1[r] - t[r]) / pc->shat[r];
         memset(pc->t0, 0, sizeof(double) * (size_t)n);
         spo_spmv_t_add(m, op->b_rowptr, op->b_colidx, op->b_val, y1, pc->t0);
-        for (int32_t i = 0; i < n; ++i) y0[i] -= pc->t0[i] * pc->dinv[i];
+        if (pc->inner_its > 0) {
+            double *d = (double *)malloc(sizeof(double) * (size_t)n);
+            spo_inner_apply(pc, pc->t0, d);
+            for (int32_t i = 0; i < n; ++i) y0[i] -= d[i];
+            free(d);
+        } else {
+            for (int32_t i = 0; i < n; ++i) y0[i] -= pc->t0[i] * pc->dinv[i];
+        }
         break;
     }
+}
+
+static void spo_pc_create(spo_pc *pc, const spo_operator *op, int pc_type, int schur_fact, int inner_its,
+                          double inner_omega)
+{
+    memset(pc, 0, sizeof *pc);
+    pc->op = op;
+    pc->pc_type = pc_type;
+    pc->schur_fact = schur_fact;
+    pc->inner_its = inner_its;
+    pc->inner_omega = inner_omega;
+    pc->dinv = (double *)malloc(sizeof(double) * (size_t)op->n);
+    pc->t0 = (double *)malloc(sizeof(double) * (size_t)op->n);
+    pc->shat = (double *)calloc(16, sizeof(double));
+    spo_jacobi_setup(op, pc->dinv);
+    if (op->m > 0) spo_schur_setup(op, pc->dinv, pc->shat, NULL);
+    if (inner_its > 0) {
+        const int32_t nnz = op->a_rowptr[op->n];
+        pc->a32 = (float *)malloc(sizeof(float) * (size_t)(nnz > 0 ? nnz : 1));
+        pc->d32 = (float *)malloc(sizeof(float) * (size_t)op->n);
+        pc->x32 = (float *)malloc(sizeof(float) * (size_t)op->n);
+        pc->y32 = (float *)malloc(sizeof(float) * (size_t)op->n);
+        pc->z32 = (float *)malloc(sizeof(float) * (size_t)op->n);
+        for (int32_t k = 0; k < nnz; ++k) pc->a32[k] = (float)op->a_val[k];
+        for (int32_t i = 0; i < op->n; ++i) pc->d32[i] = (float)pc->dinv[i];
+    }
+}
+static void spo_pc_free(spo_pc *pc)
+{
+    free(pc->dinv); free(pc->t0); free(pc->shat);
+    free(pc->a32); free(pc->d32); free(pc->x32); free(pc->y32); free(pc->z32);
 }
 
 /* Stand-alone PC application for tests: sets up, applies once, tears down. */
 int spo_pc_apply_once(const spo_operator *op, int pc_type, int schur_fact,
                       const double *x, double *y)
 {
-    spo_pc pc = {op, pc_type, schur_fact, NULL, NULL, NULL};
-    pc.dinv = (double *)malloc(sizeof(double) * (size_t)op->n);
-    pc.t0 = (double *)malloc(sizeof(double) * (size_t)op->n);
-    pc.shat = (double *)calloc(16, sizeof(double));
-    spo_jacobi_setup(op, pc.dinv);
-    if (op->m > 0) spo_schur_setup(op, pc.dinv, pc.shat, NULL);
+    spo_pc pc;
+    spo_pc_create(&pc, op, pc_type, schur_fact, 0, 1.0);
     spo_pc_apply(&pc, x, y);
-    free(pc.dinv); free(pc.t0); free(pc.shat);
+    spo_pc_free(&pc);
+    return 0;
+}
+int spo_pc_apply_inner(const spo_operator *op, int pc_type, int schur_fact, int inner_its, double inner_omega,
+                       const double *x, double *y)
+{
+    spo_pc pc;
+    spo_pc_create(&pc, op, pc_type, schur_fact, inner_its, inner_omega);
+    spo_pc_apply(&pc, x, y);
+    spo_pc_free(&pc);
     return 0;
 }
 
@@ -580,12 +672,8 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
     double *rs = (double *)calloc((size_t)mk + 2, sizeof(double));
     double *nrs = (double *)calloc((size_t)mk + 1, sizeof(double));
     double *lhh = (double *)calloc((size_t)mk + 1, sizeof(double));
-    spo_pc pc = {op, opt->pc_type, opt->schur_fact, NULL, NULL, NULL};
-    pc.dinv = (double *)malloc(sizeof(double) * (size_t)op->n);
-    pc.t0 = (double *)malloc(sizeof(double) * (size_t)op->n);
-    pc.shat = (double *)calloc(16, sizeof(double));
-    spo_jacobi_setup(op, pc.dinv);
-    if (op->m > 0) spo_schur_setup(op, pc.dinv, pc.shat, NULL);
+    spo_pc pc;
+    spo_pc_create(&pc, op, opt->pc_type, opt->schur_fact, opt->inner_its, opt->inner_omega);
 #define HH(i, j) H[(i) + (size_t)(mk + 2) * (j)]
 #define VV(j) (V + (size_t)N * (j))
 #define ZZ(j) (Z + (size_t)N * (j))
@@ -717,7 +805,7 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
 #undef VV
 #undef ZZ
     free(V); free(Z); free(tmp); free(H); free(cc); free(ss); free(rs); free(nrs); free(lhh);
-    free(pc.dinv); free(pc.t0); free(pc.shat);
+    spo_pc_free(&pc);
     return 0;
 }
 

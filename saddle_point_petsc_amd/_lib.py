@@ -80,6 +80,7 @@ def _load():
     L.spk_comm_init_local.argtypes = [vp, vp, C.c_int]
     L.spk_set_block.argtypes = [vp, C.c_int, i64, i32, i64, i32p, i32p, f64p]
     L.spk_pc_setup.argtypes = [vp, C.c_int, C.c_int]
+    L.spk_pc_set_inner.argtypes = [vp, C.c_int, C.c_double]
     L.spk_get_schur_diag.argtypes = [vp, f64p]
     L.spk_get_jacobi_diag.argtypes = [vp, f64p]
     L.spk_mult.argtypes = [vp, f64p, f64p, C.c_int]

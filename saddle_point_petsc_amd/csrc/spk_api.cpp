@@ -159,6 +159,16 @@ int spk_pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     SPK_CATCH(c)
 }
 
+int spk_pc_set_inner(spk_ctx *c, int sweeps, double omega)
+{
+    SPK_TRY(c)
+    if (sweeps < 0 || sweeps > 64 || !(omega > 0.0) || !(omega < 2.0)) spk::fail(SPK_ERR_ARG, "pc_set_inner: sweeps in [0,64], omega in (0,2)");
+    c->inner_sweeps = sweeps;
+    c->inner_omega = omega;
+    c->pc_ready = false;
+    SPK_CATCH(c)
+}
+
 int spk_get_schur_diag(spk_ctx *c, double *shat)
 {
     SPK_TRY(c)

@@ -252,6 +252,18 @@ void extract_diag_inv(const CsrDev &A, double *dinv, hipStream_t s);
 // y0 = dinv .* x0 - dinv .* (Bt y1)    (mode 1, FULL third step, recomputing D x0)
 void bt_update(int mode, const CsrDev &Bt, const double *dinv, const double *x0, const double *y1,
                double *y0, const int32_t *done, hipStream_t s);
+// FP32 inner solve (damped-Jacobi Richardson sweeps on the diagonal block of A)
+void cvt_scale_f32(const double *x, const float *d32, float omega, float *x32, float *y32, int64_t n,
+                   const int32_t *done, hipStream_t s);                       // x32 = (float)x ; y32 = omega d32 x32
+void jacobi_sweep_f32(const CsrDev &A, const float *val32, const float *d32, float omega, const float *x32,
+                      const float *yin, float *yout, const int32_t *done, hipStream_t s);
+void sweep_offdiag_f32(const CsrDev &Ao, const int32_t *rows, const float *d32, float omega, const double *xg,
+                       float *y, const int32_t *done, hipStream_t s);        // y[row] -= omega d (Ao_row . xg)
+void gather_f32(const float *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s);
+// y = (double)y32  (mode 0)  |  y -= (double)y32  (mode 1)
+void cvt_f32_out(const float *y32, double *y, int mode, int64_t n, const int32_t *done, hipStream_t s);
+void cvt_vals_f32(const double *v, float *v32, int64_t n, hipStream_t s);
+// c = x0 - Bt y1 (mode 2) | c = Bt y1 (mode 3): the vector handed to the inner solve
 // small scalar kernels
 void schur_y1(int fact, int m, const double *x1, const double *t, const double *shat, double *y1,
               const int32_t *done, hipStream_t s);
@@ -318,6 +330,10 @@ struct spk_ctx {
     bool pc_ready = false;
     spk::DevBuf<double> dinv, shat, gram;  // n_local, m, m*m
     spk::DevBuf<double> bd;                // the m rows of B D as dense vectors of stride ld (fused Schur path)
+    // FP32 inner solve (0 sweeps = plain diag(A)^-1)
+    int inner_sweeps = 0;
+    double inner_omega = 1.0;
+    spk::DevBuf<float> a32, d32, x32, y32a, y32b;
 
     // scratch
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd

@@ -924,6 +924,159 @@ void gather(const double *x, const int32_t *idx, int64_t n, double *out, const i
 }
 
 // ---------------------------------------------------------------------------
+// FP32 inner solve: damped-Jacobi Richardson sweeps y <- y + omega D^-1 (x - A y) on the
+// diagonal block, single precision throughout (BASELINE config 5).  The sweep reuses the
+// CSR stream structure (tiles, int32 columns) with a float copy of the values: 8 B per stored
+// non-zero.  Products are rounded once and summed in CSR order, the update is written with
+// FMA contraction switched off -> bit-identical to the oracle's float loop.  (HIP's __fmul_rn /
+// __fadd_rn helpers are inlined header functions that carry their own contract flag and DO fuse.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void cvt_scale_f32_kernel(const double *__restrict__ x,
+                                                                 const float *__restrict__ d32, float omega,
+                                                                 float *__restrict__ x32, float *__restrict__ y32,
+                                                                 int64_t n, const int32_t *__restrict__ done)
+{
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own (the oracle's float loop)
+    if (done && *done) return;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float xv = (float)x[i];
+        x32[i] = xv;
+        y32[i] = ((omega * d32[i]) * xv);
+    }
+}
+void cvt_scale_f32(const double *x, const float *d32, float omega, float *x32, float *y32, int64_t n,
+                   const int32_t *done, hipStream_t s)
+{
+    if (n == 0) return;
+    const int grid = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(cvt_scale_f32_kernel, dim3(grid), dim3(kThreads), 0, s, x, d32, omega, x32, y32, n, done);
+}
+
+__global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const float *__restrict__ val32,
+    const int32_t *__restrict__ tile_row, int ntiles, int tiles_per_xcd, const float *__restrict__ d32,
+    float omega, const float *__restrict__ x32, const float *__restrict__ yin, float *__restrict__ yout,
+    const int32_t *__restrict__ done)
+{
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own (the oracle's float loop)
+    if (done && *done) return;
+    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    __shared__ float prod[kCsrTile + 8];
+    const int r0 = tile_row[t], r1 = tile_row[t + 1];
+    const int nz0 = rowptr[r0], nz1 = rowptr[r1];
+    const int a0 = nz0 & ~3;
+    const int cnt = nz1 - a0;
+    if (cnt > kCsrTile) {  // one row longer than a tile
+        float acc = 0.0f;
+        for (int k = nz0 + threadIdx.x; k < nz1; k += kThreads) acc += val32[k] * yin[colidx[k]];
+        __shared__ float red[kThreads];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = kThreads / 2; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            yout[r0] = yin[r0] + ((omega * d32[r0]) * (x32[r0] - red[0]));
+        return;
+    }
+    constexpr int kSteps = kCsrTile / (kThreads * 4);
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int q = (i * kThreads + threadIdx.x) * 4;
+        if (q < cnt) {
+            const int4 c = *reinterpret_cast<const int4 *>(colidx + a0 + q);
+            const float4 v = *reinterpret_cast<const float4 *>(val32 + a0 + q);
+            float4 p;
+            p.x = (v.x * yin[c.x]);
+            p.y = (v.y * yin[c.y]);
+            p.z = (v.z * yin[c.z]);
+            p.w = (v.w * yin[c.w]);
+            *reinterpret_cast<float4 *>(prod + q) = p;
+        }
+    }
+    __syncthreads();
+    const int r = r0 + threadIdx.x;
+    if (r < r1) {
+        const int k0 = rowptr[r] - a0, k1 = rowptr[r + 1] - a0;
+        float s = 0.0f;
+        for (int k = k0; k < k1; ++k) s = (s + prod[k]);
+        yout[r] = yin[r] + ((omega * d32[r]) * (x32[r] - s));
+    }
+}
+void jacobi_sweep_f32(const CsrDev &A, const float *val32, const float *d32, float omega, const float *x32,
+                      const float *yin, float *yout, const int32_t *done, hipStream_t s)
+{
+    if (A.nrows == 0) return;
+    const int tpx = (A.ntiles + 7) / 8;
+    hipLaunchKernelGGL(jacobi_sweep_f32_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p, A.colidx.p, val32,
+                       A.tile_row.p, A.ntiles, tpx, d32, omega, x32, yin, yout, done);
+}
+
+// rows with off-rank columns: y[row] -= omega d (Ao_row . ghost values of the previous iterate)
+__global__ __launch_bounds__(kThreads) void sweep_offdiag_f32_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ val,
+    const int32_t *__restrict__ rows, int nrows, const float *__restrict__ d32, float omega,
+    const double *__restrict__ xg, float *__restrict__ y, const int32_t *__restrict__ done)
+{
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own (the oracle's float loop)
+    if (done && *done) return;
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= nrows) return;
+    float sacc = 0.0f;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) sacc = sacc + ((float)val[k] * (float)xg[colidx[k]]);
+    const int r = rows[i];
+    y[r] = y[r] - ((omega * d32[r]) * sacc);
+}
+void sweep_offdiag_f32(const CsrDev &Ao, const int32_t *rows, const float *d32, float omega, const double *xg,
+                       float *y, const int32_t *done, hipStream_t s)
+{
+    if (Ao.nrows == 0) return;
+    hipLaunchKernelGGL(sweep_offdiag_f32_kernel, dim3((Ao.nrows + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       Ao.rowptr.p, Ao.colidx.p, Ao.val.p, rows, Ao.nrows, d32, omega, xg, y, done);
+}
+
+__global__ __launch_bounds__(kThreads) void gather_f32_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx,
+                                                              int64_t n, double *__restrict__ out,
+                                                              const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) out[i] = (double)x[idx[i]];
+}
+void gather_f32(const float *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, x, idx, n, out, done);
+}
+
+__global__ __launch_bounds__(kThreads) void cvt_f32_out_kernel(const float *__restrict__ y32, double *__restrict__ y,
+                                                               int mode, int64_t n, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+        y[i] = mode == 0 ? (double)y32[i] : y[i] - (double)y32[i];
+}
+void cvt_f32_out(const float *y32, double *y, int mode, int64_t n, const int32_t *done, hipStream_t s)
+{
+    if (n == 0) return;
+    const int grid = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(cvt_f32_out_kernel, dim3(grid), dim3(kThreads), 0, s, y32, y, mode, n, done);
+}
+
+__global__ __launch_bounds__(kThreads) void cvt_vals_f32_kernel(const double *__restrict__ v, float *__restrict__ v32, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) v32[i] = (float)v[i];
+}
+void cvt_vals_f32(const double *v, float *v32, int64_t n, hipStream_t s)
+{
+    if (n == 0) return;
+    const int grid = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(cvt_vals_f32_kernel, dim3(grid), dim3(kThreads), 0, s, v, v32, n);
+}
+
+// ---------------------------------------------------------------------------
 // preconditioner pieces
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void jacobi_kernel(const double *__restrict__ dinv,
@@ -978,6 +1131,10 @@ __global__ __launch_bounds__(kThreads) void bt_update_kernel(int mode,
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < nrows; r += gridDim.x * kThreads) {
         double c = 0.0;
         for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) c += val[k] * y1[colidx[k]];
+        if (mode >= 2) {  // vectors handed to the inner solve: x0 - Bt y1 (2), Bt y1 (3)
+            y0[r] = mode == 2 ? x0[r] - c : c;
+            continue;
+        }
         const double d = dinv[r], xv = x0[r];
         y0[r] = (mode == 0) ? (xv - c) * d : xv * d - c * d;
     }

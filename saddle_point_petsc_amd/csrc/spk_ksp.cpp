@@ -14,6 +14,9 @@ struct SpkKSP_s {
     int device = 0;
     spk_opts opts;
     int32_t pc_type = SPK_PC_NONE, schur_fact = SPK_SCHUR_FULL;
+    int32_t inner_sweeps = 0;  // -fieldsplit_0_ksp_max_it with -fieldsplit_0_ksp_type richardson
+    double inner_omega = 1.0;  // -fieldsplit_0_ksp_richardson_scale
+    bool inner_richardson = false;
     bool have_ops = false, is_setup = false, has_B = false;
     bool monitor = false, print_reason = false, view = false;
     spk_result result;
@@ -206,7 +209,18 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
             if (std::string(val) != "selfp") return bad();
         } else if (key == "-pc_fieldsplit_detect_saddle_point") {
             /* implied by the nest */
-        } else if (key == "-fieldsplit_0_ksp_type" || key == "-fieldsplit_1_ksp_type") {
+        } else if (key == "-fieldsplit_0_ksp_type") {
+            if (!val) return need("a type");
+            const std::string v(val);
+            if (v == "richardson") k->inner_richardson = true;   // FP32 Jacobi-Richardson inner solve
+            else if (v == "preonly") k->inner_richardson = false;
+            else return bad();
+        } else if (key == "-fieldsplit_0_ksp_max_it" || key == "-spk_inner_sweeps") {
+            if (!val || !parse_int(val, &k->inner_sweeps)) return need("an integer");
+            if (key == "-spk_inner_sweeps") k->inner_richardson = k->inner_sweeps > 0;
+        } else if (key == "-fieldsplit_0_ksp_richardson_scale" || key == "-spk_inner_omega") {
+            if (!val || !parse_double(val, &k->inner_omega)) return need("a real");
+        } else if (key == "-fieldsplit_1_ksp_type") {
             if (!val) return need("a type");
             if (std::string(val) != "preonly") return bad();
         } else if (key == "-fieldsplit_0_pc_type" || key == "-fieldsplit_1_pc_type") {
@@ -230,7 +244,9 @@ int SpkKSPSetUp(SpkKSP k)
     if (!k->have_ops) return set_err(k, SPK_ERR_STATE, "KSPSetUp: KSPSetOperators has not been called");
     if (k->pc_type == SPK_PC_SCHUR && !k->has_B)
         return set_err(k, SPK_ERR_STATE, "KSPSetUp: -pc_type fieldsplit (schur) needs the constraint block B");
-    const int rc = spk_pc_setup(k->ctx, k->pc_type, k->schur_fact);
+    int rc = spk_pc_set_inner(k->ctx, k->inner_richardson ? k->inner_sweeps : 0, k->inner_omega);
+    if (rc != SPK_OK) return from_ctx(k, rc);
+    rc = spk_pc_setup(k->ctx, k->pc_type, k->schur_fact);
     if (rc != SPK_OK) return from_ctx(k, rc);
     k->is_setup = true;
     return SPK_OK;

@@ -340,10 +340,21 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
         for (int r = 0; r < m; ++r) sh[(size_t)r] = G[(size_t)r * m + r];
         SPK_HIP(hipMemcpy(c->shat.p, sh.data(), sh.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // FP32 copies for the inner solve
+    c->a32.release(); c->d32.release(); c->x32.release(); c->y32a.release(); c->y32b.release();
+    if (c->inner_sweeps > 0) {
+        c->a32.alloc((size_t)c->Ad.nnz, 32);
+        c->d32.alloc((size_t)c->n_local, 8);
+        c->x32.alloc((size_t)c->n_local, 8);
+        c->y32a.alloc((size_t)c->n_local, 8);
+        c->y32b.alloc((size_t)c->n_local, 8);
+        k::cvt_vals_f32(c->Ad.val.p, c->a32.p, c->Ad.nnz, s);
+        k::cvt_vals_f32(c->dinv.p, c->d32.p, c->n_local, s);
+    }
     // dense rows of B D for the fused path (Schur LOWER/FULL, even local size)
     c->bd.release();
     if (pc_type == SPK_PC_SCHUR && m > 0 && (schur_fact == SPK_SCHUR_FULL || schur_fact == SPK_SCHUR_LOWER) &&
-        c->n_local % 2 == 0) {
+        c->n_local % 2 == 0 && c->inner_sweeps == 0) {
         c->bd.alloc((size_t)c->ld * m, 16);
         k::build_bd(c->Bt, c->dinv.p, m, c->ld, c->bd.p, s);
     }
@@ -356,12 +367,62 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
 // ---------------------------------------------------------------------------
 // y = M^-1 x   (PCApply_Jacobi / PCApply_FieldSplit_Schur)
 // ---------------------------------------------------------------------------
+// y (op) A^ ^-1 x with the FP32 Richardson/Jacobi sweeps; mode 0: y = , mode 1: y -=
+static void inner_apply(spk_ctx *c, const double *x, double *y, int mode, const int32_t *done)
+{
+    hipStream_t s = c->stream;
+    const int32_t nl = c->n_local;
+    const float om = (float)c->inner_omega;
+    float *ya = c->y32a.p, *yb = c->y32b.p;
+    k::cvt_scale_f32(x, c->d32.p, om, c->x32.p, ya, nl, done, s);
+    for (int sw = 1; sw < c->inner_sweeps; ++sw) {
+        if (c->n_ghost > 0) {  // halo of the single-precision iterate, staged as doubles
+            k::gather_f32(ya, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
+            c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
+        }
+        k::jacobi_sweep_f32(c->Ad, c->a32.p, c->d32.p, om, c->x32.p, ya, yb, done, s);
+        if (c->n_ghost > 0) k::sweep_offdiag_f32(c->Ao, c->ao_rows.p, c->d32.p, om, c->xghost.p, yb, done, s);
+        std::swap(ya, yb);
+    }
+    k::cvt_f32_out(ya, y, mode, nl, done, s);
+}
+
 void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
 {
     hipStream_t s = c->stream;
     const int32_t nl = c->n_local, m = c->m;
     const double *x0 = x, *x1 = x + nl;
     double *y0 = y, *y1 = y + nl;
+    if (c->inner_sweeps > 0 && c->pc_type != SPK_PC_NONE) {
+        // same block algebra with the inner solve standing for diag(A)^-1
+        if (c->pc_type == SPK_PC_JACOBI) {
+            inner_apply(c, x0, y0, 0, done);
+            k::copy_small(x1, y1, m, done, s);
+            return;
+        }
+        switch (c->schur_fact) {
+        case SPK_SCHUR_DIAG:
+            inner_apply(c, x0, y0, 0, done);
+            k::schur_y1(SPK_SCHUR_DIAG, m, x1, nullptr, c->shat.p, y1, done, s);
+            break;
+        case SPK_SCHUR_UPPER:
+            k::schur_y1(SPK_SCHUR_UPPER, m, x1, nullptr, c->shat.p, y1, done, s);
+            k::bt_update(2, c->Bt, c->dinv.p, x0, y1, c->tmp.p, done, s);   // x0 - B^T y1
+            inner_apply(c, c->tmp.p, y0, 0, done);
+            break;
+        default:  // LOWER, FULL
+            inner_apply(c, x0, y0, 0, done);
+            k::wide_dot(c->B, y0, c->fin(c->ttmp.p), done, s);
+            c->comm->allreduce_sum(c->ttmp.p, m, s);
+            k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
+            if (c->schur_fact == SPK_SCHUR_FULL) {
+                k::bt_update(3, c->Bt, c->dinv.p, x0, y1, c->tmp.p, done, s);   // B^T y1
+                inner_apply(c, c->tmp.p, y0, 1, done);                            // y0 -= A^ ^-1 B^T y1
+            }
+            break;
+        }
+        return;
+    }
     if (c->pc_type == SPK_PC_NONE) {
         k::axpby(1.0, x, 0.0, y, (int64_t)nl + m, done, s);
         return;
@@ -476,7 +537,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const int32_t nl = c->n_local;
     // the same head kernel without a constraint block: Jacobi on K = A (the reference as written,
     // SaddlePointProblem.c:66, and BASELINE config 2): VecScale + PCApply_Jacobi + deferred Givens
-    const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && nl % 2 == 0 && nl > 0;
+    const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && nl % 2 == 0 && nl > 0 &&
+                        c->inner_sweeps == 0;
     const bool head = fused || fusedj;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
     const double *bdp = fused ? c->bd.p : nullptr;

@@ -119,7 +119,9 @@ class Context:
         self._chk(lib.spk_set_block(self.h, which, A.row_begin if which == BLOCK_A00 else 0, nrows,
                                     A.ncols, A.rowptr, A.colidx, A.val))
 
-    def pc_setup(self, pc_type, schur_fact=SCHUR_FULL):
+    def pc_setup(self, pc_type, schur_fact=SCHUR_FULL, inner_sweeps=0, inner_omega=1.0):
+        """inner_sweeps > 0: FP32 damped-Jacobi Richardson sweeps stand for diag(A)^-1."""
+        self._chk(lib.spk_pc_set_inner(self.h, inner_sweeps, inner_omega))
         self._chk(lib.spk_pc_setup(self.h, pc_type, schur_fact))
 
     def sizes(self):

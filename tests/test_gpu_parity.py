@@ -236,6 +236,38 @@ def test_single_reduction_gram_schmidt(spk, oracle, fact):
     assert relerr(x1, x2) < 1e-8 and relerr(x1, xo) < 1e-8
 
 
+@pytest.mark.parametrize("pc,fact", [("jacobi", 0), ("schur", 0), ("schur", 1), ("schur", 2), ("schur", 3)])
+def test_fp32_inner_solve(spk, oracle, pc, fact):
+    """BASELINE config 5's "mixed FP32 inner solve": k damped-Jacobi Richardson sweeps on A in single
+    precision stand for diag(A)^-1 in the preconditioner.  PC application against the oracle's float
+    restatement (same operation order: expected bitwise on the u part), then the outer FP64 FGMRES."""
+    A, f = spk.AssembleOperator_Laplace(32, 27)
+    B, g = spk.AssembleOperator_Constraints(32, 27)
+    saddle = pc == "schur"
+    rhs = np.concatenate([f, g]) if saddle else f
+    pct = spk.PC_SCHUR if saddle else spk.PC_JACOBI
+    opc = oracle.PC_SCHUR if saddle else oracle.PC_JACOBI
+    x = _x(len(rhs), 4)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        if saddle:
+            c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(pct, fact, inner_sweeps=3, inner_omega=0.8)
+        z = c.pc_apply(x)
+        sol, info = c.fgmres(rhs, rtol=1e-9)
+    zo = oracle.pc_apply_inner(A, B if saddle else None, opc, fact, 3, 0.8, x)
+    assert relerr(z, zo) < 1e-6                       # FP32 arithmetic; wide B products differ in order
+    if not saddle or fact == 0:
+        assert np.array_equal(z[:A.nrows], zo[:A.nrows])   # pure inner solve: same float operations
+    so, io = oracle.fgmres(A, rhs, B=B if saddle else None, pc_type=opc, schur_fact=fact, rtol=1e-9,
+                           inner_its=3, inner_omega=0.8)
+    assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 2
+    assert relerr(sol, so) < 1e-7
+    # and it does what it is for: far fewer outer iterations than plain diag(A)^-1
+    _, plain = oracle.fgmres(A, rhs, B=B if saddle else None, pc_type=opc, schur_fact=fact, rtol=1e-9)
+    assert info["its"] < 0.75 * plain["its"]
+
+
 def test_fgmres_rtol_1e8_iteration_counts(spk, golden_m32):
     A, f = spk.AssembleOperator_Laplace(32)
     B, g = spk.AssembleOperator_Constraints(32)
@@ -491,7 +523,7 @@ def test_driver_executable_reference_default_problem(spk, appendix_b, golden_m32
 
 
 # --------------------------------------------------------------------------- partitioned algorithm on one GPU
-def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, **kw):
+def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, inner=0, **kw):
     import threading
     grp = spk.LocalGroup(P)
     out, errs = [None] * P, []
@@ -507,7 +539,7 @@ def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, **kw):
             if with_B:
                 Bs, _ = spk.AssembleOperator_Constraints(mx, my, b, e)
                 c.set_block(spk.BLOCK_A10, Bs)
-            c.pc_setup(pc, fact)
+            c.pc_setup(pc, fact, inner_sweeps=inner, inner_omega=0.8)
             rhs = np.concatenate([rhs_full[b:e], rhs_full[n:]])
             y = c.mult(rhs)
             z = c.pc_apply(rhs)
@@ -547,6 +579,29 @@ def test_row_partitioned_solver_matches_single_rank(spk, oracle, P, single):
         assert np.array_equal(info["history"], out[0][5]["history"])     # every rank takes the same branch
     assert relerr(y, y_ref) < KERNEL_TOL and relerr(z, z_ref) < KERNEL_TOL
     assert relerr(x, xo) < 1e-8
+
+
+def test_row_partitioned_fp32_inner_solve(spk, oracle):
+    """The FP32 inner sweeps across 2 logical ranks (single-precision halo staged as doubles): the
+    preconditioner must be the same operator as on one rank up to float rounding (the off-rank
+    columns of a boundary row are added after its local ones, not in CSR order)."""
+    mx, my = 24, 26
+    A, f = spk.AssembleOperator_Laplace(mx, my)
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    rhs = np.concatenate([f, g])
+    n = A.nrows
+    out = _run_ranks(spk, 2, mx, my, spk.PC_SCHUR, spk.SCHUR_DIAG, rhs, True, inner=3, rtol=1e-9)
+    z_ref = oracle.pc_apply_inner(A, B, oracle.PC_SCHUR, 0, 3, 0.8, rhs)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=0, rtol=1e-9, inner_its=3, inner_omega=0.8)
+    z = np.zeros(n + 4); x = np.zeros(n + 4)
+    for (b, e, yr, zr, xr, info, sz) in out:
+        z[b:e], x[b:e] = zr[:-4], xr[:-4]
+        z[n:], x[n:] = zr[-4:], xr[-4:]
+        assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 2
+    assert relerr(z, z_ref) < 1e-6
+    interior = slice(2 * mx * 2, n // 2 - 2 * mx * 2)          # rows whose stencil stays on rank 0
+    assert np.array_equal(z[interior], z_ref[interior])
+    assert relerr(x, xo) < 1e-7
 
 
 def test_rccl_single_rank_communicator(spk, oracle):

@@ -197,7 +197,8 @@ def test_ksp_options_follow_the_petsc_names(spk):
     assert (k.getOptions()[0].orthog, k.getOptions()[0].cgs_refine) == (1, 1)
     k.setFromOptions("-ksp_gmres_classicalgramschmidt -ksp_gmres_cgs_refinement_type never")
     assert (k.getOptions()[0].orthog, k.getOptions()[0].cgs_refine) == (0, 0)
-    for bad in ("-ksp_type cg", "-pc_type ilu", "-ksp_rtol", "-ksp_rtol abc", "-ksp_gmres_cgs_refinement_type twice",
+    k.setFromOptions("-fieldsplit_0_ksp_type richardson -fieldsplit_0_ksp_max_it 3 -fieldsplit_0_ksp_richardson_scale 0.8")
+    for bad in ("-ksp_type cg", "-fieldsplit_0_ksp_type cg", "-pc_type ilu", "-ksp_rtol", "-ksp_rtol abc", "-ksp_gmres_cgs_refinement_type twice",
                 "-ksp_bogus 3", "-pc_fieldsplit_schur_fact_type half", "-fieldsplit_0_pc_type lu"):
         with pytest.raises(spk.SpkError):
             k.setFromOptions(bad)
