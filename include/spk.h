@@ -26,7 +26,9 @@
  *   - vectors are FP64.  A system vector is [u ; lambda]: the rank's n_local
  *     rows of the (0,0) block followed by ALL m constraint multipliers
  *     (replicated on every rank).  m = 0 when no constraint block is set.
- *   - `mem` arguments: SPK_MEM_HOST or SPK_MEM_DEVICE for the x/y/b pointers.
+ *   - `mem` arguments: SPK_MEM_HOST or SPK_MEM_DEVICE for the x/y/b pointers.  Device
+ *     vectors must come from spk_vec_create (zero-padded to a whole 16-byte pair: the
+ *     kernels read and write vectors two doubles at a time).
  */
 #ifndef SPK_H
 #define SPK_H

@@ -229,6 +229,7 @@ int spk_mult(spk_ctx *c, const double *x, double *y, int mem)
     const double *xd = stage_in(c, x, mem, c->stage_x, N);
     double *yd = mem == SPK_MEM_DEVICE ? y : c->stage_y.p;
     spk::op_mult(c, xd, yd, nullptr);
+    SPK_HIP(hipGetLastError());
     if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     SPK_HIP(hipStreamSynchronize(c->stream));
     SPK_CATCH(c)
@@ -243,6 +244,7 @@ int spk_pc_apply(spk_ctx *c, const double *x, double *y, int mem)
     const double *xd = stage_in(c, x, mem, c->stage_x, N);
     double *yd = mem == SPK_MEM_DEVICE ? y : c->stage_y.p;
     spk::op_pc_apply(c, xd, yd, nullptr);
+    SPK_HIP(hipGetLastError());
     if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     SPK_HIP(hipStreamSynchronize(c->stream));
     SPK_CATCH(c)

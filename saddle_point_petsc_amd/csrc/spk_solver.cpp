@@ -643,6 +643,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         k::axpby(1.0, b, 0.0, Vj(0), N, done, s);
         k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, done, s);
         ++cycles;
+        SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
         SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
         SPK_HIP(hipStreamSynchronize(s));
         if (st.done) break;
