@@ -268,6 +268,38 @@ def test_fp32_inner_solve(spk, oracle, pc, fact):
     assert info["its"] < 0.75 * plain["its"]
 
 
+def _six_row_constraints(spk, mx, my):
+    """4 build-defined rows + 2 more (x-moment of Uy, y-moment of Ux): exercises the m in 5..8 kernels."""
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    rows = [(B.colidx[B.rowptr[r]:B.rowptr[r + 1]], B.val[B.rowptr[r]:B.rowptr[r + 1]]) for r in range(4)]
+    hx, hy = 1.0 / (mx - 1), 1.0 / (my - 1)
+    c1, _ = rows[1]; node = c1 // 2
+    rows.append((c1, hx * hy * ((node % mx) * hx - 0.5)))            # x-moment of Uy
+    c0, _ = rows[0]; node = c0 // 2
+    rows.append((c0, hx * hy * ((node // mx) * hy - 0.5)))           # y-moment of Ux
+    rp = np.concatenate([[0], np.cumsum([len(c) for c, _ in rows])]).astype(np.int32)
+    B6 = spk.CSR(rp, np.concatenate([c for c, _ in rows]), np.concatenate([v for _, v in rows]), B.ncols)
+    return B6, np.concatenate([g, [2e-3, -1e-3]])
+
+
+@pytest.mark.parametrize("fact,fused", [(3, 1), (3, 0), (1, 1), (2, 0)])
+def test_six_constraint_rows(spk, oracle, fact, fused):
+    A, f = spk.AssembleOperator_Laplace(30, 22)
+    B6, g6 = _six_row_constraints(spk, 30, 22)
+    rhs = np.concatenate([f, g6])
+    x = _x(len(rhs), 6)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B6)
+        c.pc_setup(spk.PC_SCHUR, fact)
+        assert relerr(c.mult(x), oracle.apply_K(A, B6, x)) < KERNEL_TOL
+        assert relerr(c.pc_apply(x), oracle.pc_apply(A, B6, oracle.PC_SCHUR, fact, x)) < KERNEL_TOL
+        sol, info = c.fgmres(rhs, rtol=1e-10, fused=fused)
+    so, io = oracle.fgmres(A, rhs, B=B6, pc_type=oracle.PC_SCHUR, schur_fact=fact, rtol=1e-10)
+    _check_iteration_parity(info, io)
+    assert relerr(sol, so) < 1e-8
+
+
 def test_fgmres_rtol_1e8_iteration_counts(spk, golden_m32):
     A, f = spk.AssembleOperator_Laplace(32)
     B, g = spk.AssembleOperator_Constraints(32)
