@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--grid", type=int, default=1024, help="DMDA nodes per side")
+    ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="3: build-defined 3-D grid (BASELINE config 5 "
+                                                                       "shape, --grid nodes per side, dof 3)")
     ap.add_argument("--grid-y", type=int, default=0, help="node lines in y (default: square); e.g. 128 emulates one "
                                                           "rank's slab of the 8-GPU split on one GPU")
     ap.add_argument("--pc", default="schur-full", choices=["schur-full", "schur-lower", "schur-upper", "schur-diag", "jacobi"])
@@ -136,16 +138,24 @@ def main():
 
     M = args.grid
     My = args.grid_y or M
-    n, nnz_global = S.grid_sizes(M, My)
     t_setup = time.time()
-    rb, re_ = S.partition_slab(M, My, rank, world)
     t_asm = time.time()
     asm_threads = max(1, min(16, host_cores() // max(1, world)))   # N ranks share the host: stay far below
-    A, f = S.AssembleOperator_Laplace(M, My, rb, re_, nthreads=asm_threads)  # the box's thread limits
-    saddle = args.pc != "jacobi"
+    saddle = args.pc != "jacobi"                                   # the box's thread limits
     B = g = None
-    if saddle:
-        B, g = S.AssembleOperator_Constraints(M, My, rb, re_)
+    if args.dim == 3:
+        n = 3 * M * My * M
+        nnz_global = 9 * (3 * M - 2) * (3 * My - 2) * (3 * M - 2)
+        rb, re_ = S.partition_slab3d(M, My, M, rank, world)
+        A, f = S.AssembleOperator_Laplace3D(M, My, M, rb, re_, nthreads=asm_threads)
+        if saddle:
+            B, g = S.AssembleOperator_Constraints3D(M, My, M, rb, re_)
+    else:
+        n, nnz_global = S.grid_sizes(M, My)
+        rb, re_ = S.partition_slab(M, My, rank, world)
+        A, f = S.AssembleOperator_Laplace(M, My, rb, re_, nthreads=asm_threads)
+        if saddle:
+            B, g = S.AssembleOperator_Constraints(M, My, rb, re_)
     t_asm = time.time() - t_asm
     t_up = time.time()
     ctx = S.Context(local_rank)
@@ -205,7 +215,7 @@ def main():
     acc_ms = ctx.time_kernel("spmv_acc", 0, 20, args.spmv_reps)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-    if os.path.exists(tpath) and world == 1 and M == 1024 and My == 1024:
+    if os.path.exists(tpath) and world == 1 and M == 1024 and My == 1024 and args.dim == 2:
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_" + ctx.spmv_info()["format"])
         except Exception:  # noqa: BLE001
@@ -219,7 +229,7 @@ def main():
 
     its_per_s = args.steps / elapsed
     nnzB_local = B.nnz if saddle else 0
-    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart) \
+    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, B.nrows) \
         if (saddle and args.inner_sweeps == 0) else None
     out = {
         "metric": METRIC,
@@ -234,10 +244,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{M}x{My} DMDA node grid, dof 2 (n={n}, nnz(A)={nnz_global}), "
-                               + ("saddle K=[A B^T;B 0] with 4 constraint rows, " if saddle else "K=A, ")
+        "config": {"workload": (f"{M}x{My} DMDA node grid, dof 2" if args.dim == 2 else
+                                f"{M}x{My}x{M} node grid (build-defined 3-D generator), dof 3")
+                               + f" (n={n}, nnz(A)={nnz_global}), "
+                               + (f"saddle K=[A B^T;B 0] with {B.nrows} constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
-                   "grid": M, "rows": n + (4 if saddle else 0), "pc": args.pc, "restart": args.restart,
+                   "grid": M, "rows": n + (B.nrows if saddle else 0), "dim": args.dim, "pc": args.pc, "restart": args.restart,
                    "inner_fp32_sweeps": args.inner_sweeps,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,

@@ -42,6 +42,24 @@ int SpkAssembleOperator_Constraints(int mx, int my, int64_t row_begin, int64_t r
                                     int32_t *colidx, double *val);
 int SpkAssembleRHS_Constraints(double *g4);
 
+/* ---- 3-D input generator: BUILD-DEFINED, NOT IN THE REFERENCE -------------------------------
+ * The reference is 2-D only (#define DIM 2, include/Discretization.h:8).  BASELINE config 5 asks
+ * for a 3-D grid and the reference's help string points to PETSc's ksp/ex42.c (main.c:1); these
+ * routines carry the 2-D definitions above to Q1 hexahedra: mx x my x mz nodes on [0,1]^3, dof 3,
+ * natural ordering row = ((k*my + j)*mx + i)*3 + c, 27-point x 3 x 3 pattern with zeros stored
+ * (nnz = 9 (3mx-2)(3my-2)(3mz-2)), same truncated Gauss abscissa, stress form with
+ * D = diag(2,2,2,1,1,1), body force (1,2,3), homogeneous Dirichlet on all six faces; six
+ * constraint rows (component means + first moments).  A slab is a range of whole node PLANES
+ * (3*mx*my rows each), as spk_partition_slab(mz, 3*mx*my, ...) deals them. */
+int SpkAssemblySizes3D(int mx, int my, int mz, int64_t *nrows, int64_t *nnz);
+int64_t SpkAssemblySlabNnz3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end);
+int SpkAssembleOperator_Laplace3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end, int32_t *rowptr,
+                                  int32_t *colidx, double *val, double *f, int apply_bc, int nthreads);
+int64_t SpkConstraintsSlabNnz3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end);
+int SpkAssembleOperator_Constraints3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end, int32_t *rowptr,
+                                      int32_t *colidx, double *val);
+int SpkAssembleRHS_Constraints3D(double *g6);
+
 /* Legacy-VTK ASCII output of the solution on the node grid: what WriteVTK(da_u, u,
  * "test.vtk") at /root/reference/src/SaddlePointProblem.c:22 is meant to produce.  The
  * reference's writer (Visulaization.c:3-67) emits points and polygons only and never the

@@ -153,6 +153,39 @@ def assemble_constraints(mx, my=None):
     return CSR(rowptr, colidx, val, 2 * mx * my), g
 
 
+def assemble3d(mx, my=None, mz=None, bc=True):
+    """3-D input generator (BUILD-DEFINED, not in the reference): A, f on an mx x my x mz node grid."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    L = lib()
+    L.spo3_grid_sizes.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.spo3_assemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p]
+    n, nnz = C.c_int64(), C.c_int64()
+    L.spo3_grid_sizes(mx, my, mz, C.byref(n), C.byref(nnz))
+    rowptr = np.zeros(n.value + 1, np.int32)
+    colidx = np.zeros(nnz.value, np.int32)
+    val = np.zeros(nnz.value)
+    f = np.zeros(n.value)
+    assert L.spo3_assemble(mx, my, mz, int(bc), rowptr, colidx, val, f) == 0
+    return CSR(rowptr, colidx, val, n.value), f
+
+
+def assemble_constraints3d(mx, my=None, mz=None):
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    L = lib()
+    L.spo3_constraint_nnz.restype = C.c_int64
+    L.spo3_constraint_nnz.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.spo3_assemble_B.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p]
+    nnz = L.spo3_constraint_nnz(mx, my, mz)
+    rowptr = np.zeros(7, np.int32)
+    colidx = np.zeros(nnz, np.int32)
+    val = np.zeros(nnz)
+    g = np.zeros(6)
+    L.spo3_assemble_B(mx, my, mz, rowptr, colidx, val, g)
+    return CSR(rowptr, colidx, val, 3 * mx * my * mz), g
+
+
 def _operator(A, B=None):
     op = Operator()
     op.n = A.nrows

@@ -107,6 +107,14 @@ def _load():
     L.SpkConstraintsSlabNnz.argtypes = [C.c_int, C.c_int, i64, i64]
     L.SpkAssembleOperator_Constraints.argtypes = [C.c_int, C.c_int, i64, i64, i32p, i32p, f64p]
     L.SpkAssembleRHS_Constraints.argtypes = [f64p]
+    L.SpkAssemblySizes3D.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.SpkAssemblySlabNnz3D.restype = i64
+    L.SpkAssemblySlabNnz3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64]
+    L.SpkAssembleOperator_Laplace3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i32p, i32p, f64p, vp, C.c_int, C.c_int]
+    L.SpkConstraintsSlabNnz3D.restype = i64
+    L.SpkConstraintsSlabNnz3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64]
+    L.SpkAssembleOperator_Constraints3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i32p, i32p, f64p]
+    L.SpkAssembleRHS_Constraints3D.argtypes = [f64p]
     L.SpkWriteVTK.argtypes = [C.c_int, C.c_int, f64p, C.c_char_p]
     L.SpkFormStressOperatorQ12D.argtypes = [f64p, f64p, f64p]
     L.SpkFormLaplaceRHSQ12D.argtypes = [f64p, f64p]

@@ -74,6 +74,45 @@ def FormLaplaceRHSQ12D(xe):
     return Fe
 
 
+def AssembleOperator_Laplace3D(mx, my=None, mz=None, row_begin=0, row_end=None, apply_bc=True, nthreads=0):
+    """BUILD-DEFINED 3-D input generator (the reference is 2-D only; see include/spk_assembly.h):
+    A (CSR slab of whole node planes, global columns) and f on an mx x my x mz node grid, dof 3."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n, nnz = C.c_int64(), C.c_int64()
+    _chk(lib.SpkAssemblySizes3D(mx, my, mz, C.byref(n), C.byref(nnz)), "SpkAssemblySizes3D")
+    row_end = n.value if row_end is None else row_end
+    nz = lib.SpkAssemblySlabNnz3D(mx, my, mz, row_begin, row_end)
+    if nz < 0:
+        raise SpkError(-1, "row range must consist of whole node planes")
+    nl = row_end - row_begin
+    rowptr = np.zeros(nl + 1, np.int32)
+    colidx = np.zeros(nz, np.int32)
+    val = np.zeros(nz)
+    f = np.zeros(nl)
+    _chk(lib.SpkAssembleOperator_Laplace3D(mx, my, mz, row_begin, row_end, rowptr, colidx, val, f.ctypes.data,
+                                           int(apply_bc), nthreads), "SpkAssembleOperator_Laplace3D")
+    return CSR(rowptr, colidx, val, n.value, row_begin), f
+
+
+def AssembleOperator_Constraints3D(mx, my=None, mz=None, row_begin=0, row_end=None):
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n = 3 * mx * my * mz
+    row_end = n if row_end is None else row_end
+    nz = lib.SpkConstraintsSlabNnz3D(mx, my, mz, row_begin, row_end)
+    if nz < 0:
+        raise SpkError(-1, "column range must consist of whole node planes (grid >= 3^3)")
+    rowptr = np.zeros(7, np.int32)
+    colidx = np.zeros(nz, np.int32)
+    val = np.zeros(nz)
+    _chk(lib.SpkAssembleOperator_Constraints3D(mx, my, mz, row_begin, row_end, rowptr, colidx, val),
+         "SpkAssembleOperator_Constraints3D")
+    g = np.zeros(6)
+    _chk(lib.SpkAssembleRHS_Constraints3D(g), "SpkAssembleRHS_Constraints3D")
+    return CSR(rowptr, colidx, val, n, 0), g
+
+
 def WriteVTK(mx, my, u, filename):
     """Legacy-VTK file with the node grid and the solution field (the reference's
     WriteVTK, SaddlePointProblem.c:22, never wrote the field)."""
@@ -87,4 +126,11 @@ def partition_slab(mx, my, rank, nranks):
     """Rows of `rank` when the my node lines are dealt in contiguous slabs."""
     b, e = C.c_int64(), C.c_int64()
     _chk(lib.spk_partition_slab(my, 2 * mx, rank, nranks, C.byref(b), C.byref(e)), "spk_partition_slab")
+    return b.value, e.value
+
+
+def partition_slab3d(mx, my, mz, rank, nranks):
+    """Rows of `rank` when the mz node planes are dealt in contiguous slabs (z-slabs)."""
+    b, e = C.c_int64(), C.c_int64()
+    _chk(lib.spk_partition_slab(mz, 3 * mx * my, rank, nranks, C.byref(b), C.byref(e)), "spk_partition_slab")
     return b.value, e.value

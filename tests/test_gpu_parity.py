@@ -636,6 +636,65 @@ def test_row_partitioned_fp32_inner_solve(spk, oracle):
     assert relerr(x, xo) < 1e-7
 
 
+def test_3d_grid_config5_shape(spk, oracle):
+    """BASELINE config 5 in miniature: 3-D grid (build-defined generator), dof 3 (81 entries per row:
+    no 2x2 blocks -> CSR stream kernel), halo-exchange SpMV over 2 z-slabs, FGMRES with the mixed
+    FP32 inner solve, and the six-row saddle system on one rank."""
+    mx, my, mz = 10, 9, 12
+    A, f = spk.AssembleOperator_Laplace3D(mx, my, mz)
+    B, g = spk.AssembleOperator_Constraints3D(mx, my, mz)
+    Ao = oracle.CSR(A.rowptr, A.colidx, A.val, A.ncols)
+    Bo = oracle.CSR(B.rowptr, B.colidx, B.val, B.ncols)
+    x = _x(A.nrows, 11)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        assert c.spmv_info()["format"] == "csr"
+        assert np.array_equal(c.mult(x), oracle.spmv(Ao, x))                      # bitwise
+        c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.8)
+        u, info = c.fgmres(f, rtol=1e-9)
+        uo, io = oracle.fgmres(Ao, f, pc_type=oracle.PC_JACOBI, rtol=1e-9, inner_its=3, inner_omega=0.8)
+        assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 1 and relerr(u, uo) < 1e-7
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        assert relerr(c.mult(np.concatenate([x, g])), oracle.apply_K(Ao, Bo, np.concatenate([x, g]))) < KERNEL_TOL
+        sol, info = c.fgmres(rhs, rtol=1e-10)
+        so, io = oracle.fgmres(Ao, rhs, B=Bo, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10)
+        _check_iteration_parity(info, io)
+        assert relerr(sol, so) < 1e-8
+    # two z-slabs (halo = one node plane per side), FP32 inner solve inside the partitioned loop
+    import threading
+    grp = spk.LocalGroup(2)
+    out, errs = [None, None], []
+
+    def work(r):
+        try:
+            b, e = spk.partition_slab3d(mx, my, mz, r, 2)
+            As, fs = spk.AssembleOperator_Laplace3D(mx, my, mz, b, e)
+            cc = spk.Context(0)
+            cc.comm_init_local(grp, r)
+            cc.set_block(spk.BLOCK_A00, As)
+            cc.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.8)
+            y = cc.mult(x[b:e])
+            ur, inf = cc.fgmres(fs, rtol=1e-9)
+            out[r] = (b, e, y, ur, inf, cc.sizes())
+            cc.close()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            raise
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    grp.close()
+    assert not errs, errs
+    y = np.zeros(A.nrows); u2 = np.zeros(A.nrows)
+    for (b, e, yr, ur, inf, sz) in out:
+        y[b:e], u2[b:e] = yr, ur
+        assert sz["n_ghost"] == 3 * mx * my and inf["reason"] == 2
+    assert relerr(y, oracle.spmv(Ao, x)) < KERNEL_TOL and relerr(u2, uo) < 1e-6
+
+
 def test_rccl_single_rank_communicator(spk, oracle):
     """RCCL path with nranks = 1 (all a 1-GPU box can run): unique id, init,
     in-stream all-reduce of the Krylov scalars."""
