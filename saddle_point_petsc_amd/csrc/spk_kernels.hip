@@ -1372,19 +1372,23 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t 
 // iteration-head kernel, where it overlaps with that kernel's streaming.
 __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2)
 {
-    __shared__ double Hc[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2];
+    __shared__ double Hc[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
     KrylovState *st = ka.st;
     if (st->done) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
     double *Hg = ka.H + (size_t)ldh * loc;  // column loc
+    // every global value the serial chain needs is fetched here, in parallel, once
     for (int j = threadIdx.x; j <= loc; j += blockDim.x) {
         Hc[j] = dots[j];
         ccs[j] = ka.cc[j];
         sss[j] = ka.ss[j];
     }
+    if (threadIdx.x == 32) sc[0] = *nrm2;
+    if (threadIdx.x == 33) sc[1] = ka.rs[loc];
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const double tt = sqrt(*nrm2);
+    const double rs_loc = sc[1];
+    const double tt = sqrt(sc[0]);
     if (isnan(tt) || isinf(tt)) {  // KSPCheckNorm: KSP_DIVERGED_NANORINF
         st->rnorm = tt;
         st->reason = SPK_DIVERGED_NANORINF;
@@ -1392,7 +1396,7 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
         return;
     }
     // happy breakdown test
-    double hapbnd = fabs(tt / ka.rs[loc]);
+    double hapbnd = fabs(tt / rs_loc);
     if (hapbnd > 1e-30) hapbnd = 1e-30;
     const int hapend = !(tt > hapbnd);
     Hc[loc + 1] = tt;
@@ -1417,10 +1421,10 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
         const double c = h0 / d, sn = h1 / d;
         ka.cc[loc] = c;
         ka.ss[loc] = sn;
-        ka.rs[loc + 1] = -sn * ka.rs[loc];
-        ka.rs[loc] = c * ka.rs[loc];
+        ka.rs[loc + 1] = -sn * rs_loc;
+        ka.rs[loc] = c * rs_loc;
         Hc[loc] = c * h0 + sn * h1;
-        rnorm = fabs(ka.rs[loc + 1]);
+        rnorm = fabs(sn * rs_loc);
     } else {
         rnorm = 0.0;
     }
