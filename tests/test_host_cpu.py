@@ -26,6 +26,39 @@ def test_library_exports_every_declared_symbol(spk, header):
     assert not missing, f"{header}: not exported by libspk.so: {missing}"
 
 
+def test_headers_are_plain_c_and_link(spk, tmp_path):
+    """The boundary is a C ABI: the three headers must compile as C99 (the reference's language is
+    C11) and a C program must link against libspk.so and call the host-only entry points."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "spk.h"
+#include "spk_ksp.h"
+#include "spk_assembly.h"
+int main(void) {
+    spk_opts o; spk_default_opts(&o);
+    int64_t n = 0, nnz = 0, b = 0, e = 0;
+    if (SpkAssemblySizes(4, 4, &n, &nnz)) return 2;
+    if (spk_partition_slab(4, 8, 1, 2, &b, &e)) return 3;
+    SpkKSP ksp; if (SpkKSPCreate(0, &ksp)) return 4;
+    const char *opts[] = {"-ksp_type", "fgmres", "-ksp_rtol", "1e-9"};
+    if (SpkKSPSetFromOptions(ksp, 4, opts)) return 5;
+    SpkKSPDestroy(&ksp);
+    printf("%d %d %g %lld %lld %lld %lld\n", spk_version(), o.restart, o.rtol, (long long)n, (long long)nnz,
+           (long long)b, (long long)e);
+    return 0;
+}
+""")
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(spk.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lspk", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["100", "30", "1e-05", "32", "400", "16", "32"]
+
+
 def test_version_and_defaults(spk):
     assert spk.lib.spk_version() == 100
     o = spk.default_opts()
@@ -203,6 +236,35 @@ def test_split_reproduces_the_slab_product(spk, oracle, P):
         for i in range(e - b):
             y[b + i] = dv[drp[i]:drp[i + 1]] @ xl[dci[drp[i]:drp[i + 1]]] + ov[orp[i]:orp[i + 1]] @ xg[oci[orp[i]:orp[i + 1]]]
     assert np.allclose(y, y_ref, rtol=1e-13, atol=1e-15)
+
+
+def test_split_property_random_csr(spk):
+    """Property test (hypothesis): for any CSR slab with arbitrary global columns the diagonal /
+    off-rank split reproduces the slab product, ghosts are sorted, unique and off-range."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40), st.integers(0, 30), st.integers(0, 6), st.integers(0, 2 ** 31 - 1))
+    def check(nrows, before, maxlen, seed):
+        rng = np.random.default_rng(seed)
+        ncols = before + nrows + int(rng.integers(0, 30))
+        lens = rng.integers(0, maxlen + 1, nrows)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        colidx = rng.integers(0, ncols, rowptr[-1]).astype(np.int32)
+        val = rng.standard_normal(rowptr[-1])
+        A = spk.CSR(rowptr, colidx, val, ncols, row_begin=before)
+        drp, dci, dv, orp, oci, ov, ga = _split(spk, A)
+        lo, hi = before, before + nrows
+        assert np.all(np.diff(ga) > 0) and np.all((ga < lo) | (ga >= hi))
+        x = rng.standard_normal(ncols)
+        xl, xg = x[lo:hi], x[ga] if len(ga) else np.zeros(1)
+        for i in range(nrows):
+            ref = val[rowptr[i]:rowptr[i + 1]] @ x[colidx[rowptr[i]:rowptr[i + 1]]]
+            got = dv[drp[i]:drp[i + 1]] @ xl[dci[drp[i]:drp[i + 1]]] + ov[orp[i]:orp[i + 1]] @ xg[oci[orp[i]:orp[i + 1]]]
+            assert got == pytest.approx(ref, rel=1e-12, abs=1e-12)
+        assert drp[-1] + orp[-1] == rowptr[-1]
+
+    check()
 
 
 def test_partition_slab_matches_petsc_dmda_split(spk):
