@@ -197,12 +197,25 @@ struct Finish {
     double *out;
 };
 
+// off-rank part folded into the SpMV epilogue (rowptr over ALL local rows; nullptr: none)
+struct OffDiag {
+    const int32_t *rowptr, *colidx;
+    const double *val, *xg;
+};
+// packed halo values written by the producer of a vector instead of a gather launch: up to four
+// contiguous row ranges (slab partitions send whole node lines / planes)
+struct SendRanges {
+    int n;  // 0: none
+    int32_t r0[4], len[4], off[4];
+    double *buf;
+};
+
 // y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-          const int32_t *done, hipStream_t s, bool accumulate = false);
+          const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
 // same product from the 2x2-blocked copy (bitwise the same sums: CSR order is kept)
 void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-               const int32_t *done, hipStream_t s, bool accumulate = false);
+               const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
 // y[rows[i]] += Ao_row_i . xg   (compressed off-rank block)
 void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
@@ -282,7 +295,8 @@ void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const do
 // previous iteration's Givens step in workgroup 0 (loc_prev < 0: none)
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
-                const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s);
+                const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
+                const SendRanges *sr = nullptr);
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)
@@ -313,6 +327,9 @@ struct spk_ctx {
     spk::BcsrDev Ab;               // 2x2-blocked copy of Ad when the structure allows
     int spmv_format = 0;           // 0 = CSR stream kernel, 1 = BCSR
     spk::DevBuf<int32_t> ao_rows;  // local row of each compressed Ao row
+    spk::DevBuf<int32_t> ao_rowptr_full;  // Ao row pointers over all local rows (SpMV epilogue form)
+    spk::k::SendRanges send_ranges{};     // halo rows as contiguous ranges, when they are
+    spk::k::OffDiag offdiag() const { return spk::k::OffDiag{ao_rowptr_full.p, Ao.colidx.p, Ao.val.p, xghost.p}; }
     bool have_A = false, have_B = false;
 
     // constraint block: B (m x n_local) in column windows, B^T (n_local x m) by rows

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
     const double *__restrict__ val, const int32_t *__restrict__ tile_row, int ntiles,
     int tiles_per_xcd, const double *__restrict__ x, double *__restrict__ y,
     const int32_t *__restrict__ bt_rowptr, const int32_t *__restrict__ bt_colidx,
-    const double *__restrict__ bt_val, const double *__restrict__ lam, int accumulate,
+    const double *__restrict__ bt_val, const double *__restrict__ lam, int accumulate, OffDiag od,
     const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -200,6 +200,8 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
         if (threadIdx.x == 0) {
             out1 = 0.0;
             for (int j = 0; j < T / 64; ++j) out1 += red[j];
+            if (od.rowptr)
+                for (int k = od.rowptr[r0]; k < od.rowptr[r0 + 1]; ++k) out1 += od.val[k] * od.xg[od.colidx[k]];
             if (bt_rowptr)
                 for (int k = bt_rowptr[r0]; k < bt_rowptr[r0 + 1]; ++k) out1 += bt_val[k] * lam[bt_colidx[k]];
             if (accumulate) out1 += y[r0];
@@ -242,6 +244,8 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
         const int k0 = rowptr[r] - a0, k1 = rowptr[r + 1] - a0;
         double s = 0.0;
         for (int k = k0; k < k1; ++k) s += prod[k];
+        if (od.rowptr)  // off-rank columns of this row (ghost values already exchanged)
+            for (int k = od.rowptr[r]; k < od.rowptr[r + 1]; ++k) s += od.val[k] * od.xg[od.colidx[k]];
         if (bt_rowptr)
             for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
         if (accumulate) s += y[r];  // y pre-loaded with B^T lambda by the fused PC kernel
@@ -250,13 +254,14 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
 }
 
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-          const int32_t *done, hipStream_t s, bool accumulate)
+          const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *od)
 {
     if (A.nrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
+    const OffDiag o = od ? *od : OffDiag{nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads>), dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p,
                        A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, done);
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, o, done);
 }
 
 // ---------------------------------------------------------------------------
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ bt_rowptr,
     const int32_t *__restrict__ bt_colidx, const double *__restrict__ bt_val,
-    const double *__restrict__ lam, const int32_t *__restrict__ done)
+    const double *__restrict__ lam, OffDiag od, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -319,6 +324,8 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
         if (threadIdx.x < 2) {
             const int r = 2 * br0 + threadIdx.x;
             double o = ((red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + red[4 * threadIdx.x + 2]) + red[4 * threadIdx.x + 3];
+            if (od.rowptr)
+                for (int k = od.rowptr[r]; k < od.rowptr[r + 1]; ++k) o += od.val[k] * od.xg[od.colidx[k]];
             if (bt_rowptr)
                 for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) o += bt_val[k] * lam[bt_colidx[k]];
             if (ACC) o += y[r];
@@ -366,6 +373,8 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
             s += p.y;
         }
         const int r = 2 * br0 + lr;
+        if (od.rowptr)  // off-rank columns of this row (ghost values already exchanged)
+            for (int k = od.rowptr[r]; k < od.rowptr[r + 1]; ++k) s += od.val[k] * od.xg[od.colidx[k]];
         if (bt_rowptr)
             for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
         if (ACC) s += y[r];
@@ -374,19 +383,20 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
 }
 
 void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-               const int32_t *done, hipStream_t s, bool accumulate)
+               const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *odp)
 {
     if (A.nbrows == 0) return;
     const int tpx = (A.ntiles + 7) / 8;
+    const OffDiag od = odp ? *odp : OffDiag{nullptr, nullptr, nullptr, nullptr};
     // non-temporal loads on the matrix planes (read once per SpMV): 70.7 -> 61.3 us in the same run
     if (accumulate)
         hipLaunchKernelGGL((spmv_bcsr_kernel<true, true>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p,
                            A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, done);
+                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done);
     else
         hipLaunchKernelGGL((spmv_bcsr_kernel<true, false>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p,
                            A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, done);
+                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done);
 }
 
 // compressed off-rank block: few short rows, one thread per row
@@ -1467,7 +1477,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
     const double *__restrict__ dinv, const double *__restrict__ bd, int64_t ldb,
     const double *__restrict__ shat, const double *__restrict__ gram, int fact, int64_t nl, int m,
     double *__restrict__ z, double *__restrict__ c, KrylovArrays ka, int loc_prev,
-    const double *__restrict__ dots_prev, const int32_t *__restrict__ done)
+    const double *__restrict__ dots_prev, SendRanges sr, const int32_t *__restrict__ done)
 {
     // c == nullptr: Jacobi head (K = A, m = 0): v = w'/||w'||, z = D v, nothing pre-loaded
     if (*done) return;
@@ -1533,20 +1543,29 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
             cc.y = s1 / d.y;
             reinterpret_cast<double2 *>(c)[i] = cc;
         }
+        // rows a neighbour needs go straight into the packed halo buffer (no gather launch)
+        for (int q = 0; q < sr.n; ++q) {
+            const int64_t e = 2 * i - sr.r0[q];
+            if (e >= 0 && e < sr.len[q]) sr.buf[sr.off[q] + e] = zz.x;
+            if (e + 1 >= 0 && e + 1 < sr.len[q]) sr.buf[sr.off[q] + e + 1] = zz.y;
+        }
     }
 }
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
-                const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s)
+                const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
+                const SendRanges *srp)
 {
     const int64_t n2 = nl / 2;
     const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
+    SendRanges sr{};
+    if (srp) sr = *srp;
     if (m <= 4)
         hipLaunchKernelGGL(fused_head_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
-                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, done);
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, done);
     else
         hipLaunchKernelGGL(fused_head_kernel<8>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
-                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, done);
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, done);
 }
 
 // -ksp_gmres_cgs_refinement_type: mode 2 (always) refines unless done; mode 1 (ifneeded)

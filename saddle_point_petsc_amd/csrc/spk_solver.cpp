@@ -203,6 +203,27 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     }
     c->send_idx.upload(send_idx.data(), send_idx.size(), 8);
     c->send_buf.alloc(send_idx.size(), 8);
+    // off-rank part in "SpMV epilogue" form: row pointers over all local rows
+    c->ao_rowptr_full.release();
+    if (c->n_ghost > 0) c->ao_rowptr_full.upload(sp.o_rowptr.data(), sp.o_rowptr.size(), 8);
+    // halo rows as contiguous ranges (slab partitions): lets the producer of z fill send_buf itself
+    c->send_ranges = k::SendRanges{};
+    {
+        bool ok = !c->peers.empty() && c->peers.size() <= 4;
+        for (size_t p = 0; ok && p < c->peers.size(); ++p) {
+            const int64_t a = c->send_off[p], b = c->send_off[p + 1];
+            for (int64_t i = a + 1; ok && i < b; ++i) ok = send_idx[(size_t)i] == send_idx[(size_t)i - 1] + 1;
+            if (ok) {
+                c->send_ranges.r0[p] = b > a ? send_idx[(size_t)a] : 0;
+                c->send_ranges.len[p] = (int32_t)(b - a);
+                c->send_ranges.off[p] = (int32_t)a;
+            }
+        }
+        if (ok) {
+            c->send_ranges.n = (int)c->peers.size();
+            c->send_ranges.buf = c->send_buf.p;
+        }
+    }
     c->xghost.alloc((size_t)c->n_ghost, 8);
     c->have_A = true;
     c->pc_ready = false;
@@ -296,9 +317,10 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done)
         k::gather(x, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
         c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
     }
-    if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
-    else k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s);
-    if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, y, done, s);
+    const k::OffDiag od = c->offdiag();
+    const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;   // off-rank columns in the same kernel
+    if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
+    else k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
     if (m > 0) {
         k::wide_dot(c->B, x, c->fin(y + nl), done, s);
         c->comm->allreduce_sum(y + nl, m, s);
@@ -567,17 +589,19 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             if (fused) {
                 // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part);
                 // workgroup 0 also runs the Givens step of iteration loc-1
+                const bool packed = c->n_ghost > 0 && c->send_ranges.n > 0;   // head fills the halo buffer itself
                 k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
-                              c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s);
+                              c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
+                              packed ? &c->send_ranges : nullptr);
                 last = loc;
-                // w += A z0
+                // w += A z0 (halo exchange, then diagonal and off-rank columns in ONE kernel)
+                const k::OffDiag od = c->offdiag();
                 if (c->n_ghost > 0) {
-                    k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
+                    if (!packed) k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
                 }
-                if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true);
-                else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true);
-                if (c->n_ghost > 0) k::spmv_offdiag(c->Ao, c->ao_rows.p, c->xghost.p, w, done, s);
+                if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
+                else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
             } else if (fusedj) {
                 k::fused_head(Vj(loc), nrmbuf(loc + 1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER,
                               nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s);
