@@ -165,6 +165,12 @@ def main():
         ids = [S.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init_rccl(rank, world, ids[0])
+    if use_dist and world > 1 and os.environ.get("SPK_BENCH_PEER", "1") != "0":
+        # Krylov all-reduces and halo rows written straight into the peers' HBM over xGMI by the
+        # solver's kernels; falls back (collectively) to the communicator above when a rank cannot
+        # map a peer's window
+        if not ctx.comm_enable_peer() and rank == 0:
+            print(f"[bench] peer-store collectives off ({ctx.last_error()}); using {ctx.comm_backend()}", file=sys.stderr)
     ctx.set_block(S.BLOCK_A00, A)
     if saddle:
         ctx.set_block(S.BLOCK_A10, B)
@@ -261,7 +267,8 @@ def main():
                    "inner_fp32_sweeps": args.inner_sweeps,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,
-                   "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},
+                   "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
+                   "collectives": ctx.comm_backend()},
         "spmv_gbps": achieved,
         "spmv_ms": spmv_ms,
         "residual_after_steps": info["rnorm"] / info["rnorm0"] if info["rnorm0"] else None,

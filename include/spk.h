@@ -135,6 +135,20 @@ typedef struct spk_host_comm {
     int (*allgather)(void *user, const void *in, void *out, int64_t bytes_each);
 } spk_host_comm;
 int spk_comm_init_host(spk_ctx *ctx, int rank, int nranks, const spk_host_comm *cb);
+/* Peer-store collectives (call after spk_comm_init_*, before spk_set_block; collective over the
+ * ranks).  The Krylov all-reduces (<= 64 doubles) and the halo rows are then written by the solver's
+ * own kernels straight into windows of the peers' HBM over xGMI -- 8-byte {sequence, payload}
+ * granules that are their own arrival flags: one network traversal, no RCCL launch, and where the
+ * kernel allows it no launch at all (the all-reduce rides in the finish of the reducing kernel).
+ * Sums are formed in rank order on every rank: all ranks hold the same bits.  The windows are
+ * uncached device memory shared through HIP IPC; the communicator set before stays in place for
+ * set-up traffic and as the fallback.  *enabled = 1 when every rank mapped every window and a
+ * self-test all-reduce gave the right sums everywhere, else 0 (the previous backend keeps
+ * working; spk_comm_backend() tells which one is active).  2..8 ranks.  Device-side waits are
+ * bounded (SPK_PEER_TIMEOUT_MS, default 30000): a rank that never arrives turns into SPK_ERR_COMM. */
+int spk_comm_enable_peer(spk_ctx *ctx, int32_t *enabled);
+/* "self" | "rccl" | "host-callback" | "local" | "peer-store" */
+const char *spk_comm_backend(const spk_ctx *ctx);
 /* In-process logical ranks on one device (parity tests of the partitioned
  * algorithm on a 1-GPU box): a group is shared by `nranks` contexts, each
  * driven by its own host thread. */

@@ -78,6 +78,9 @@ def _load():
     L.spk_local_group_create.argtypes = [C.POINTER(vp), C.c_int]
     L.spk_local_group_destroy.argtypes = [vp]
     L.spk_comm_init_local.argtypes = [vp, vp, C.c_int]
+    L.spk_comm_enable_peer.argtypes = [vp, C.POINTER(i32)]
+    L.spk_comm_backend.restype = C.c_char_p
+    L.spk_comm_backend.argtypes = [vp]
     L.spk_set_block.argtypes = [vp, C.c_int, i64, i32, i64, i32p, i32p, f64p]
     L.spk_pc_setup.argtypes = [vp, C.c_int, C.c_int]
     L.spk_pc_set_inner.argtypes = [vp, C.c_int, C.c_double]

@@ -2,6 +2,7 @@
 // Argument checks, error capture (exceptions never cross the ABI), staging of
 // host vectors.  The work is in spk_solver.cpp / spk_kernels.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -144,6 +145,24 @@ int spk_comm_init_local(spk_ctx *c, spk_local_group *grp, int rank)
     SPK_CATCH(c)
 }
 
+int spk_comm_enable_peer(spk_ctx *c, int32_t *enabled)
+{
+    SPK_TRY(c)
+    if (enabled) *enabled = 0;
+    if (c->have_A) spk::fail(SPK_ERR_STATE, "comm_enable_peer: must precede spk_set_block");
+    const char *off = getenv("SPK_COMM_PEER");
+    if (!(off && !strcmp(off, "0")) && c->comm->size() > 1 && strcmp(c->comm->name(), "peer-store") != 0) {
+        std::string why;
+        spk::Comm *inner = c->comm.release();
+        c->comm.reset(spk::make_peer_comm(inner, c->device, &why));
+        c->err = why;  // informational when the backend stayed off
+    }
+    if (enabled) *enabled = strcmp(c->comm->name(), "peer-store") == 0;
+    SPK_CATCH(c)
+}
+
+const char *spk_comm_backend(const spk_ctx *c) { return c && c->comm ? c->comm->name() : "self"; }
+
 int spk_set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
                   const int32_t *rowptr, const int32_t *colidx, const double *val)
 {
@@ -232,6 +251,7 @@ int spk_mult(spk_ctx *c, const double *x, double *y, int mem)
     SPK_HIP(hipGetLastError());
     if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     SPK_HIP(hipStreamSynchronize(c->stream));
+    c->comm->check(c->stream);
     SPK_CATCH(c)
 }
 
@@ -247,6 +267,7 @@ int spk_pc_apply(spk_ctx *c, const double *x, double *y, int mem)
     SPK_HIP(hipGetLastError());
     if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     SPK_HIP(hipStreamSynchronize(c->stream));
+    c->comm->check(c->stream);
     SPK_CATCH(c)
 }
 

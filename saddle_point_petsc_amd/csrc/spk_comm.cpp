@@ -15,7 +15,9 @@
 //              partitioned algorithm (parity tests); host barriers, slow.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -137,6 +139,7 @@ public:
     {
         if (comm_) (void)rccl().CommDestroy(comm_);
     }
+    const char *name() const override { return "rccl"; }
     int rank() const override { return rank_; }
     int size() const override { return n_; }
     void allreduce_sum(double *dev, int count, hipStream_t s) override
@@ -195,6 +198,7 @@ public:
         }
         g->barrier();
     }
+    const char *name() const override { return "local"; }
     int rank() const override { return rank_; }
     int size() const override { return g_->nranks; }
     void allreduce_sum(double *dev, int count, hipStream_t s) override
@@ -257,6 +261,7 @@ private:
 class HostCbComm : public Comm {
 public:
     HostCbComm(int rank, int nranks, const spk_host_comm &cb) : rank_(rank), n_(nranks), cb_(cb) {}
+    const char *name() const override { return "host-callback"; }
     int rank() const override { return rank_; }
     int size() const override { return n_; }
     void allreduce_sum(double *dev, int count, hipStream_t s) override
@@ -308,7 +313,327 @@ private:
     spk_host_comm cb_;
 };
 
+// ---------------------------------------------------------------------------
+// Peer-store backend: one-shot all-reduce and halo exchange written straight into
+// the peers' memory over xGMI by the solver's own kernels (spk_kernels.hip, "granules").
+// Each rank owns two windows of UNCACHED device memory, mapped into every peer
+// through HIP IPC (ranks in other processes) or used directly (logical ranks of one
+// process): the all-reduce window (fixed size) and the halo staging (sized by the
+// halo plan).  `inner` -- RCCL or the host transport -- carries the set-up traffic
+// and stays the fallback: the backend is only switched on when every rank mapped
+// every window AND a self-test all-reduce returned the right sums on every rank.
+// ---------------------------------------------------------------------------
+struct WinInfo {
+    int64_t pid;
+    uint64_t ptr;
+    hipIpcMemHandle_t handle;
+    int32_t ok, device;
+    int64_t n_ghost;
+    int64_t recv_off_for[k::kPeerMax];  // where rank p's rows land in my ghost array (-1: not a peer)
+};
+
+class PeerComm : public Comm {
+public:
+    PeerComm(Comm *inner, int device) : inner_(inner), device_(device), P_(inner->size()), me_(inner->rank())
+    {
+        const char *t = getenv("SPK_PEER_TIMEOUT_MS");
+        timeout_ms_ = t ? (uint32_t)std::max(1, atoi(t)) : 30000u;
+        err_.alloc(4);
+        std::memset(ar_map_, 0, sizeof ar_map_);
+        std::memset(halo_map_, 0, sizeof halo_map_);
+    }
+    ~PeerComm() override
+    {
+        close_maps(ar_map_, ar_own_);
+        close_maps(halo_map_, halo_own_);
+        if (ar_own_) (void)hipFree(ar_own_);
+        if (halo_own_) (void)hipFree(halo_own_);
+    }
+    Comm *release_inner() { return inner_.release(); }
+    const char *name() const override { return "peer-store"; }
+    int rank() const override { return me_; }
+    int size() const override { return P_; }
+
+    // maps the all-reduce windows and runs the self-test; false (with *why) when any rank failed
+    bool enable(std::string *why)
+    {
+        const size_t bytes = sizeof(unsigned long long) * (size_t)k::kArSlots * P_ * k::kArGranules;
+        std::string mywhy;
+        bool ok = alloc_window(&ar_own_, bytes, &mywhy);
+        ok = share_window(ar_own_, ok, 0, nullptr, ar_map_, nullptr, &mywhy) && ok;
+        ok = agree(ok);
+        if (ok) {
+            // self-test: two all-reduces (two slots) of values that differ per rank and per position
+            // on a stream of its own: logical ranks of one process would queue behind each other on the
+            // null stream, and a rank's kernel waits for the other ranks' kernels
+            DevBuf<double> buf;
+            buf.alloc(64);
+            hipStream_t ts = nullptr;
+            SPK_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+            for (int round = 0; round < 2 && ok; ++round) {
+                std::vector<double> h(64), r(64);
+                for (int i = 0; i < 64; ++i) h[(size_t)i] = (double)(me_ + 1) * (i + 1 + round) + 0.25 * round;
+                SPK_HIP(hipMemcpy(buf.p, h.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+                k::PeerAR a = next_ar();
+                a.timeout_ms = 5000;
+                k::peer_allreduce(a, buf.p, 64, ts);
+                SPK_HIP(hipStreamSynchronize(ts));
+                SPK_HIP(hipMemcpy(r.data(), buf.p, 64 * sizeof(double), hipMemcpyDeviceToHost));
+                for (int i = 0; i < 64 && ok; ++i) {
+                    const double want = 0.5 * P_ * (P_ + 1) * (i + 1 + round) + 0.25 * round * P_;
+                    if (r[(size_t)i] != want) {
+                        ok = false;
+                        mywhy = "self-test all-reduce returned a wrong sum";
+                    }
+                }
+                if (error_word()) {
+                    ok = false;
+                    mywhy = "self-test all-reduce timed out";
+                }
+            }
+            (void)hipStreamDestroy(ts);
+            ok = agree(ok);
+        }
+        if (!ok && why) *why = mywhy.empty() ? "another rank could not map the windows" : mywhy;
+        return ok;
+    }
+
+    void allreduce_sum(double *dev, int count, hipStream_t s) override
+    {
+        if (count <= 0) return;
+        if (2 * count > k::kArGranules) {
+            inner_->allreduce_sum(dev, count, s);
+            return;
+        }
+        k::peer_allreduce(next_ar(), dev, count, s);
+    }
+    k::PeerAR fused_allreduce(int count) override
+    {
+        if (!fuse_ || count <= 0 || 2 * count > k::kArGranules) return k::PeerAR{};
+        return next_ar();
+    }
+    void setup_halo(int32_t n_ghost, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
+                    const std::vector<int64_t> &recv_off) override
+    {
+        inner_->setup_halo(n_ghost, peers, send_off, recv_off);
+        close_maps(halo_map_, halo_own_);
+        if (halo_own_) (void)hipFree(halo_own_);
+        halo_own_ = nullptr;
+        halo_ok_ = false;
+        n_ghost_ = n_ghost;
+        std::string why;
+        bool ok = peers.size() <= 4;
+        // staging: two parities x n_ghost doubles x two granules
+        const size_t bytes = sizeof(unsigned long long) * 4 * (size_t)std::max<int32_t>(n_ghost, 1);
+        ok = alloc_window(&halo_own_, bytes, &why) && ok;
+        int64_t roff[k::kPeerMax];
+        for (int p = 0; p < k::kPeerMax; ++p) roff[p] = -1;
+        for (size_t i = 0; i < peers.size(); ++i)
+            if (peers[i] < k::kPeerMax) roff[peers[i]] = recv_off[i];
+        std::vector<WinInfo> all;
+        ok = share_window(halo_own_, ok, n_ghost, roff, halo_map_, &all, &why) && ok;
+        if (ok) {
+            halo_peers_ = peers;
+            halo_send_off_ = send_off;
+            halo_recv_off_ = recv_off;
+            for (size_t i = 0; i < peers.size() && ok; ++i) {
+                const WinInfo &w = all[(size_t)peers[i]];
+                halo_remote_ng_[i] = w.n_ghost;
+                halo_remote_off_[i] = w.recv_off_for[me_];
+                const int64_t ns = send_off[i + 1] - send_off[i];
+                if (ns > 0 && (w.recv_off_for[me_] < 0 || w.recv_off_for[me_] + ns > w.n_ghost)) {
+                    ok = false;
+                    why = "halo plans of two ranks do not match";
+                }
+            }
+        }
+        halo_ok_ = agree(ok);
+    }
+    void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
+                  double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override
+    {
+        if (peers.empty()) return;
+        if (!halo_ok_ || peers != halo_peers_ || send_off != halo_send_off_ || recv_off != halo_recv_off_) {
+            inner_->exchange(sendbuf, peers, send_off, recvbuf, recv_off, s);
+            return;
+        }
+        k::PeerHalo h{};
+        h.npeers = (int)peers.size();
+        h.seq = ++halo_seq_;
+        h.timeout_ms = timeout_ms_;
+        const int par = (int)(h.seq & 1u);
+        for (size_t i = 0; i < peers.size(); ++i) {
+            h.remote[i] = halo_map_[peers[i]] + 2 * ((size_t)par * (size_t)halo_remote_ng_[i] + (size_t)halo_remote_off_[i]);
+            h.send_off[i] = send_off[i];
+            h.recv_off[i] = recv_off[i];
+        }
+        h.send_off[peers.size()] = send_off.back();
+        h.recv_off[peers.size()] = recv_off.back();
+        h.mine = halo_own_ + 2 * (size_t)par * (size_t)n_ghost_;
+        h.err = err_.p;
+        k::peer_exchange(h, sendbuf, recvbuf, s);
+    }
+    void check(hipStream_t s) override
+    {
+        (void)s;
+        if (error_word()) fail(SPK_ERR_COMM, "peer-store collective timed out after %u ms waiting for another rank", timeout_ms_);
+    }
+    void host_allgather(const void *in, void *out, size_t bytes_each) override { inner_->host_allgather(in, out, bytes_each); }
+    void host_allgatherv(const void *in, size_t bytes_in, std::vector<std::vector<char>> &out) override
+    {
+        inner_->host_allgatherv(in, bytes_in, out);
+    }
+    void set_fuse(bool f) { fuse_ = f; }
+
+private:
+    k::PeerAR next_ar()
+    {
+        k::PeerAR a{};
+        a.P = P_;
+        a.me = me_;
+        a.seq = ++ar_seq_;
+        a.timeout_ms = timeout_ms_;
+        for (int p = 0; p < P_; ++p) a.win[p] = ar_map_[p];
+        a.err = err_.p;
+        return a;
+    }
+    int32_t error_word()
+    {
+        int32_t e = 0;
+        SPK_HIP(hipMemcpy(&e, err_.p, sizeof e, hipMemcpyDeviceToHost));
+        return e;
+    }
+    bool agree(bool ok)
+    {
+        std::vector<int32_t> all((size_t)P_);
+        const int32_t mine = ok ? 1 : 0;
+        inner_->host_allgather(&mine, all.data(), sizeof mine);
+        for (int32_t v : all) ok = ok && v != 0;
+        return ok;
+    }
+    static bool alloc_window(unsigned long long **p, size_t bytes, std::string *why)
+    {
+        *p = nullptr;
+        // uncached (MTYPE UC): a peer's stores must be seen by my polls without any cache maintenance
+        if (hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                *p = nullptr;
+                *why = "no uncached / fine-grained device memory for the window";
+                return false;
+            }
+        }
+        if (hipMemset(*p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            *why = "window could not be cleared";
+            return false;
+        }
+        return true;
+    }
+    // publishes my window, maps everybody else's; collective (one host all-gather)
+    bool share_window(unsigned long long *own, bool ok, int64_t n_ghost, const int64_t *roff, unsigned long long **map,
+                      std::vector<WinInfo> *all_out, std::string *why)
+    {
+        WinInfo mine{};
+        mine.pid = (int64_t)getpid();
+        mine.ptr = (uint64_t)(uintptr_t)own;
+        mine.device = device_;
+        mine.n_ghost = n_ghost;
+        for (int p = 0; p < k::kPeerMax; ++p) mine.recv_off_for[p] = roff ? roff[p] : -1;
+        if (ok && own && hipIpcGetMemHandle(&mine.handle, own) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+            *why = "hipIpcGetMemHandle failed on the window";
+        }
+        mine.ok = ok ? 1 : 0;
+        std::vector<WinInfo> all((size_t)P_);
+        inner_->host_allgather(&mine, all.data(), sizeof mine);
+        bool good = true;
+        for (int p = 0; p < P_; ++p) {
+            map[p] = nullptr;
+            const WinInfo &w = all[(size_t)p];
+            if (p == me_) {
+                map[p] = own;
+                good = good && own != nullptr && w.ok != 0;
+            } else if (w.ok == 0) {
+                good = false;
+            } else if (w.pid == mine.pid) {
+                // logical ranks of ONE process: their streams are coupled by the null stream and by
+                // hipFree's device-wide wait, so one rank's host thread can block behind another
+                // rank's kernel that is waiting for it -- a deadlock until the time-out
+                good = false;
+                *why = "ranks share a process (peer-store needs one process per rank)";
+            } else if (w.ok != 1) {
+                good = false;
+            } else {
+                void *q = nullptr;
+                if (hipIpcOpenMemHandle(&q, w.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                    (void)hipGetLastError();
+                    good = false;
+                    *why = "hipIpcOpenMemHandle failed for rank " + std::to_string(p);
+                } else {
+                    map[p] = (unsigned long long *)q;
+                    opened_.push_back(q);
+                }
+            }
+        }
+        if (all_out) *all_out = all;
+        return good;
+    }
+    void close_maps(unsigned long long **map, unsigned long long *own)
+    {
+        for (int p = 0; p < k::kPeerMax; ++p) {
+            void *q = map[p];
+            if (q && q != own) {
+                auto it = std::find(opened_.begin(), opened_.end(), q);
+                if (it != opened_.end()) {
+                    (void)hipIpcCloseMemHandle(q);
+                    opened_.erase(it);
+                }
+            }
+            map[p] = nullptr;
+        }
+    }
+
+    std::unique_ptr<Comm> inner_;
+    int device_, P_, me_;
+    uint32_t timeout_ms_ = 30000, ar_seq_ = 0, halo_seq_ = 0;
+    bool fuse_ = true, halo_ok_ = false;
+    DevBuf<int32_t> err_;
+    unsigned long long *ar_own_ = nullptr, *halo_own_ = nullptr;
+    unsigned long long *ar_map_[k::kPeerMax], *halo_map_[k::kPeerMax];
+    std::vector<void *> opened_;
+    int32_t n_ghost_ = 0;
+    std::vector<int> halo_peers_;
+    std::vector<int64_t> halo_send_off_, halo_recv_off_;
+    int64_t halo_remote_ng_[4] = {0, 0, 0, 0}, halo_remote_off_[4] = {0, 0, 0, 0};
+};
+
 }  // namespace
+
+Comm *make_peer_comm(Comm *inner, int device, std::string *why)
+{
+    if (inner->size() < 2 || inner->size() > k::kPeerMax) {
+        if (why) *why = "peer-store backend needs 2.." + std::to_string(k::kPeerMax) + " ranks";
+        return inner;
+    }
+    auto *pc = new PeerComm(inner, device);
+    bool ok = false;
+    try {
+        ok = pc->enable(why);
+    } catch (const Error &e) {
+        // a failure inside the collective set-up cannot be agreed on any more: give the caller the message
+        if (why) *why = e.msg;
+        ok = false;
+    }
+    if (!ok) {
+        Comm *back = pc->release_inner();
+        delete pc;
+        return back;
+    }
+    return pc;
+}
 
 Comm *make_host_comm(int rank, int nranks, const spk_host_comm &cb) { return new HostCbComm(rank, nranks, cb); }
 Comm *make_self_comm() { return new SelfComm(); }

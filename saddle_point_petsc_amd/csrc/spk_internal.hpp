@@ -108,6 +108,33 @@ struct WideDev {
 };
 
 // ---------------------------------------------------------------------------
+// peer-store windows (one-shot collectives over xGMI, spk_comm.cpp / spk_kernels.hip)
+// ---------------------------------------------------------------------------
+namespace k {
+constexpr int kPeerMax = 8;        // ranks of one node
+constexpr int kArSlots = 4;        // all-reduce slots in flight (a rank is never more than one ahead)
+constexpr int kArGranules = 128;   // 8-byte {seq, half} granules per rank and slot = 64 doubles
+// One-shot all-reduce: every rank stores its values as tagged granules into EVERY rank's window
+// (win[p] = rank p's window as mapped here) and sums what arrived in its own, in rank order.
+struct PeerAR {
+    int P, me;                     // P == 0: off
+    uint32_t seq, timeout_ms;
+    unsigned long long *win[kPeerMax];
+    int32_t *err;                  // set to 1 by a poll that timed out
+};
+// Halo exchange in the same style: my segment for peer i goes to remote[i] (the place in that
+// rank's staging window where it expects my rows), what I expect arrives in `mine`.
+struct PeerHalo {
+    int npeers;                    // 0: off
+    uint32_t seq, timeout_ms;
+    unsigned long long *remote[4];
+    const unsigned long long *mine;
+    int64_t send_off[5], recv_off[5];
+    int32_t *err;
+};
+}  // namespace k
+
+// ---------------------------------------------------------------------------
 // collectives
 // ---------------------------------------------------------------------------
 struct HaloPlan;
@@ -116,6 +143,17 @@ public:
     virtual ~Comm() {}
     virtual int rank() const { return 0; }
     virtual int size() const { return 1; }
+    // called once the halo plan of the (0,0) block is known (collective)
+    virtual void setup_halo(int32_t n_ghost, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
+                            const std::vector<int64_t> &recv_off)
+    { (void)n_ghost; (void)peers; (void)send_off; (void)recv_off; }
+    // all-reduce performed INSIDE the reducing kernel's finish (peer-store backend): returns the
+    // window set for the next all-reduce of `count` values, or P == 0 when the backend cannot
+    // (the caller then calls allreduce_sum after the kernel)
+    virtual k::PeerAR fused_allreduce(int count) { (void)count; return k::PeerAR{}; }
+    // throws SPK_ERR_COMM when a device-side wait of this backend has timed out (call after a sync)
+    virtual void check(hipStream_t s) { (void)s; }
+    virtual const char *name() const { return "self"; }
     // in-place sum over ranks of `count` doubles in device memory, stream-ordered
     virtual void allreduce_sum(double *dev, int count, hipStream_t s) { (void)dev; (void)count; (void)s; }
     // exchange of packed halo segments: sendbuf[send_off[p]..] -> peer p,
@@ -137,6 +175,9 @@ Comm *make_self_comm();
 Comm *make_rccl_comm(int rank, int nranks, const void *id128, int device);
 Comm *make_local_comm(spk_local_group *grp, int rank);
 Comm *make_host_comm(int rank, int nranks, const spk_host_comm &cb);
+// wraps `inner` (kept for set-up traffic and as the fallback) with the peer-store backend when every
+// rank can map every other rank's window; returns `inner` itself otherwise (*why says why)
+Comm *make_peer_comm(Comm *inner, int device, std::string *why);
 
 // ---------------------------------------------------------------------------
 // host-side partition results
@@ -258,6 +299,9 @@ void axpby(double a, const double *x, double b, double *y, int64_t n, const int3
 void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s);
 // gather x[idx[i]] -> out[i]
 void gather(const double *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s);
+// peer-store collectives (stand-alone launches; the fused forms live in the reducing kernels)
+void peer_allreduce(const PeerAR &a, double *buf, int count, hipStream_t s);
+void peer_exchange(const PeerHalo &h, const double *sendbuf, double *recvbuf, hipStream_t s);
 // Jacobi / Schur pieces
 void jacobi(const double *dinv, const double *x, double *y, int64_t n, const int32_t *done, hipStream_t s);
 void extract_diag_inv(const CsrDev &A, double *dinv, hipStream_t s);

@@ -934,6 +934,117 @@ void gather(const double *x, const int32_t *idx, int64_t n, double *out, const i
 }
 
 // ---------------------------------------------------------------------------
+// Peer-store collectives over xGMI (replace MPI_Allreduce / VecScatter inside
+// KSPSolve; SURVEY 8(e): the payloads are <= 64 doubles and one node line, so
+// latency is everything).  Data travels as 8-byte GRANULES {sequence number,
+// 32 payload bits} written by ONE system-scope store each into the receiver's
+// window (uncached device memory mapped into every peer): a granule is its own
+// arrival flag, so there is no fence and no second round trip -- the receiver
+// spins on the tag of each granule it needs.  Every poll is bounded (the peer
+// may have died): on time-out the error word is raised and the kernel ends.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// waits until the granule at p carries `seq`; lo = its payload.  false: timed out, or an earlier
+// wait of this context did (the error word is sticky: once a peer is lost every later wait gives up
+// at once, so a whole enqueued restart cycle drains in one time-out, not one per collective).
+__device__ __forceinline__ bool granule_wait(const unsigned long long *p, uint32_t seq, uint32_t timeout_ms, uint32_t &lo,
+                                             const int32_t *err)
+{
+    unsigned long long g = ld_sys(p);
+    if ((uint32_t)(g >> 32) != seq) {
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        for (;;) {
+            __builtin_amdgcn_s_sleep(2);
+            g = ld_sys(p);
+            if ((uint32_t)(g >> 32) == seq) break;
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                wall_clock64() - t0 > (unsigned long long)timeout_ms * 100000ull) {
+                lo = 0;
+                return false;
+            }
+        }
+    }
+    lo = (uint32_t)g;
+    return true;
+}
+__device__ __forceinline__ double join_halves(uint32_t lo, uint32_t hi)
+{
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Threads 0 .. 2*count-1 of the calling workgroup (count <= 64; a double's two halves sit in
+// adjacent lanes) sum vals[0..count) over the ranks into out[0..count): every rank adds the
+// P contributions in rank order, its own included, so all ranks hold the same bits.
+// No barrier inside; vals may be LDS or global, out may alias vals.
+__device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const double *vals, int count, double *out)
+{
+    const int t = threadIdx.x;
+    if (t >= 2 * count) return;
+    const int slot = (int)(a.seq & (kArSlots - 1));
+    const uint32_t half = reinterpret_cast<const uint32_t *>(vals)[t];
+    const unsigned long long g = ((unsigned long long)a.seq << 32) | half;
+    const size_t mine = ((size_t)slot * a.P + a.me) * kArGranules + t;
+    for (int p = 0; p < a.P; ++p) st_sys(a.win[p] + mine, g);
+    const unsigned long long *own = a.win[a.me] + (size_t)slot * a.P * kArGranules + t;
+    double sum = 0.0;
+    bool ok = true;
+    for (int p = 0; p < a.P; ++p) {
+        uint32_t lo;
+        ok = granule_wait(own + (size_t)p * kArGranules, a.seq, a.timeout_ms, lo, a.err) && ok;
+        const uint32_t other = __shfl_xor(lo, 1, kWave);
+        sum += join_halves(lo, other);  // meaningful in even lanes
+    }
+    if (!(t & 1)) out[t >> 1] = sum;
+    if (!ok) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(2 * 64) void peer_allreduce_kernel(PeerAR a, double *buf, int count)
+{
+    peer_allreduce_block(a, buf, count, buf);
+}
+void peer_allreduce(const PeerAR &a, double *buf, int count, hipStream_t s)
+{
+    if (count < 1 || 2 * count > kArGranules) fail(SPK_ERR_COMM, "peer all-reduce: %d values (1..%d)", count, kArGranules / 2);
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(128), 0, s, a, buf, count);
+}
+
+// one thread per granule: send first, then wait for the granule with the same index of my own staging
+__global__ __launch_bounds__(kThreads) void peer_exchange_kernel(PeerHalo h, const double *__restrict__ sendbuf,
+                                                                 double *__restrict__ recvbuf)
+{
+    const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t ns2 = 2 * h.send_off[h.npeers], nr2 = 2 * h.recv_off[h.npeers];
+    if (g < ns2) {
+        const int64_t e = g >> 1;
+        int p = 0;
+        while (p + 1 < h.npeers && e >= h.send_off[p + 1]) ++p;
+        const uint32_t half = reinterpret_cast<const uint32_t *>(sendbuf)[g];
+        st_sys(h.remote[p] + (g - 2 * h.send_off[p]), ((unsigned long long)h.seq << 32) | half);
+    }
+    if (g < nr2) {
+        uint32_t lo;
+        const bool ok = granule_wait(h.mine + g, h.seq, h.timeout_ms, lo, h.err);
+        const uint32_t other = __shfl_xor(lo, 1, kWave);
+        if (!(g & 1)) recvbuf[g >> 1] = join_halves(lo, other);
+        if (!ok) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+void peer_exchange(const PeerHalo &h, const double *sendbuf, double *recvbuf, hipStream_t s)
+{
+    const int64_t g = 2 * std::max(h.send_off[h.npeers], h.recv_off[h.npeers]);
+    if (g == 0) return;
+    hipLaunchKernelGGL(peer_exchange_kernel, dim3((unsigned)((g + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, h,
+                       sendbuf, recvbuf);
+}
+
+// ---------------------------------------------------------------------------
 // FP32 inner solve: damped-Jacobi Richardson sweeps y <- y + omega D^-1 (x - A y) on the
 // diagonal block, single precision throughout (BASELINE config 5).  The sweep reuses the
 // CSR stream structure (tiles, int32 columns) with a float copy of the values: 8 B per stored

@@ -225,6 +225,7 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
         }
     }
     c->xghost.alloc((size_t)c->n_ghost, 8);
+    c->comm->setup_halo(c->n_ghost, c->peers, c->send_off, c->recv_off);  // collective
     c->have_A = true;
     c->pc_ready = false;
     c->ensure_vectors();
@@ -313,7 +314,7 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done)
 {
     hipStream_t s = c->stream;
     const int32_t nl = c->n_local, m = c->m;
-    if (c->n_ghost > 0) {
+    if (!c->peers.empty()) {  // a rank may have rows to send without needing any itself
         k::gather(x, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
         c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
     }
@@ -398,7 +399,7 @@ static void inner_apply(spk_ctx *c, const double *x, double *y, int mode, const 
     float *ya = c->y32a.p, *yb = c->y32b.p;
     k::cvt_scale_f32(x, c->d32.p, om, c->x32.p, ya, nl, done, s);
     for (int sw = 1; sw < c->inner_sweeps; ++sw) {
-        if (c->n_ghost > 0) {  // halo of the single-precision iterate, staged as doubles
+        if (!c->peers.empty()) {  // halo of the single-precision iterate, staged as doubles
             k::gather_f32(ya, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
             c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
         }
@@ -589,14 +590,14 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             if (fused) {
                 // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part);
                 // workgroup 0 also runs the Givens step of iteration loc-1
-                const bool packed = c->n_ghost > 0 && c->send_ranges.n > 0;   // head fills the halo buffer itself
+                const bool packed = c->send_ranges.n > 0;   // head fills the halo buffer itself
                 k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
                               c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
                               packed ? &c->send_ranges : nullptr);
                 last = loc;
                 // w += A z0 (halo exchange, then diagonal and off-rank columns in ONE kernel)
                 const k::OffDiag od = c->offdiag();
-                if (c->n_ghost > 0) {
+                if (!c->peers.empty()) {
                     if (!packed) k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
                 }
@@ -670,6 +671,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
         SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
         SPK_HIP(hipStreamSynchronize(s));
+        c->comm->check(s);  // a peer that never arrived: SPK_ERR_COMM instead of a wrong answer
         if (st.done) break;
     }
     const auto t1 = std::chrono::steady_clock::now();

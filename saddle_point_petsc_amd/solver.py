@@ -114,6 +114,20 @@ class Context:
     def comm_init_local(self, group, rank):
         self._chk(lib.spk_comm_init_local(self.h, group.h, rank))
 
+    def comm_enable_peer(self):
+        """Peer-store collectives over xGMI on top of the communicator set before (collective).
+        Returns True when they are active, False when the previous backend stays (see
+        spk_comm_enable_peer in include/spk.h)."""
+        on = C.c_int32()
+        self._chk(lib.spk_comm_enable_peer(self.h, C.byref(on)))
+        return bool(on.value)
+
+    def last_error(self):
+        return lib.spk_last_error(self.h).decode()
+
+    def comm_backend(self):
+        return lib.spk_comm_backend(self.h).decode()
+
     def set_block(self, which, A):
         nrows = A.nrows
         self._chk(lib.spk_set_block(self.h, which, A.row_begin if which == BLOCK_A00 else 0, nrows,

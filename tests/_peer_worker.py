@@ -1,0 +1,96 @@
+"""One rank of a multi-PROCESS run on ONE GPU (launched by torch.distributed.run, gloo):
+each process owns a row slab, all share device 0.  RCCL refuses two ranks on one device, so
+the communicator is the host-callback transport over gloo; on top of it the peer-store
+backend maps the other processes' windows through HIP IPC -- the production mechanism, with
+device 0's HBM standing in for the xGMI peers.  Every case is run with the collectives
+staged through the host (reference) and written by the solver's kernels (peer-store);
+results go to <out>/rank<r>.npz for the test to compare.  Test infrastructure."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir, mode = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch  # noqa: F401  (before libspk: see bench.py)
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    import saddle_point_petsc_amd as S
+
+    res = {}
+    if mode == "timeout":
+        # rank 0 multiplies (halo exchange + all-reduce) while the others stay away: bounded wait
+        mx = my = 12
+        b, e = S.partition_slab(mx, my, rank, world)
+        A, _ = S.AssembleOperator_Laplace(mx, my, b, e)
+        Bs, _ = S.AssembleOperator_Constraints(mx, my, b, e)
+        c = S.Context(0)
+        c.comm_init_torch(dist, rank, world)
+        assert c.comm_enable_peer(), c.last_error()
+        c.set_block(S.BLOCK_A00, A)
+        c.set_block(S.BLOCK_A10, Bs)
+        msg, code = "", 0
+        if rank == 0:
+            try:
+                c.mult(np.ones(A.nrows + 4))
+            except S.SpkError as ex:
+                msg, code = str(ex), ex.code
+        dist.barrier()
+        c.close()
+        json.dump({"msg": msg, "code": code}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+        dist.destroy_process_group()
+        return
+
+    # (name, dim, grid, pc, fact, inner sweeps, fused)
+    cases = [("schur_full", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
+             ("schur_lower_unfused", 2, (24, 26), S.PC_SCHUR, S.SCHUR_LOWER, 0, 0),
+             ("jacobi", 2, (24, 26), S.PC_JACOBI, 0, 0, 1),
+             ("schur_diag_fp32", 2, (24, 26), S.PC_SCHUR, S.SCHUR_DIAG, 3, 1),
+             ("jacobi_3d_fp32", 3, (10, 9, 12), S.PC_JACOBI, 0, 3, 1)]
+    for name, dim, grid, pc, fact, inner, fused in cases:
+        saddle = pc == S.PC_SCHUR
+        if dim == 2:
+            mx, my = grid
+            b, e = S.partition_slab(mx, my, rank, world)
+            A, f = S.AssembleOperator_Laplace(mx, my, b, e)
+            Bs, g = S.AssembleOperator_Constraints(mx, my, b, e) if saddle else (None, np.zeros(0))
+        else:
+            mx, my, mz = grid
+            b, e = S.partition_slab3d(mx, my, mz, rank, world)
+            A, f = S.AssembleOperator_Laplace3D(mx, my, mz, b, e)
+            Bs, g = None, np.zeros(0)
+        rhs = np.concatenate([f, g])
+        xin = np.sin(0.37 * np.arange(b, e))
+        xin = np.concatenate([xin, 0.5 + np.arange(len(g))])
+        for peer in (0, 1):
+            c = S.Context(0)
+            c.comm_init_torch(dist, rank, world)
+            if peer:
+                assert c.comm_enable_peer(), c.last_error()
+            backend = c.comm_backend()
+            c.set_block(S.BLOCK_A00, A)
+            if saddle:
+                c.set_block(S.BLOCK_A10, Bs)
+            c.pc_setup(pc, fact, inner_sweeps=inner, inner_omega=0.8)
+            y = c.mult(xin)
+            z = c.pc_apply(xin)
+            x, info = c.fgmres(rhs, rtol=1e-9, fused=fused)
+            k = f"{name}/{peer}/"
+            res[k + "y"], res[k + "z"], res[k + "x"] = y, z, x
+            res[k + "hist"] = info["history"]
+            res[k + "meta"] = np.array([b, e, info["its"], info["reason"], int(backend == "peer-store"),
+                                        c.sizes()["n_ghost"]], np.int64)
+            c.close()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

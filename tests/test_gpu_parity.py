@@ -613,6 +613,116 @@ def test_row_partitioned_solver_matches_single_rank(spk, oracle, P, single):
     assert relerr(x, xo) < 1e-8
 
 
+def _launch_peer_worker(tmp_path, P, mode, port, env_extra=None, timeout=280):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(P),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tests", "_peer_worker.py"), str(tmp_path), mode],
+                         capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P):
+    """P PROCESSES on this GPU, each owning a row slab; the peer-store backend maps the other
+    processes' windows through HIP IPC and the solver's own kernels write the Krylov all-reduces and
+    the halo rows into them (tests/_peer_worker.py).  Checked per case: every rank holds the same
+    scalars bit for bit (same residual history), the result equals the single-rank oracle to the
+    usual bars, and with two ranks -- where the host-staged all-reduce adds in the same order -- it
+    is bit-identical to the host-staged run."""
+    _launch_peer_worker(tmp_path, P, "cases", 29650 + P)
+    R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
+    cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_lower_unfused", 2, (24, 26), oracle.PC_SCHUR, 1, 0),
+             ("jacobi", 2, (24, 26), oracle.PC_JACOBI, 0, 0), ("schur_diag_fp32", 2, (24, 26), oracle.PC_SCHUR, 0, 3),
+             ("jacobi_3d_fp32", 3, (10, 9, 12), oracle.PC_JACOBI, 0, 3)]
+    for name, dim, grid, pc, fact, inner in cases:
+        saddle = pc == oracle.PC_SCHUR
+        if dim == 2:
+            A, f = spk.AssembleOperator_Laplace(*grid)
+            B, g = spk.AssembleOperator_Constraints(*grid) if saddle else (None, np.zeros(0))
+        else:
+            A, f = spk.AssembleOperator_Laplace3D(*grid)
+            B, g = None, np.zeros(0)
+        n, m = A.nrows, len(g)
+        Ao = oracle.CSR(A.rowptr, A.colidx, A.val, A.ncols)
+        Bo = oracle.CSR(B.rowptr, B.colidx, B.val, B.ncols) if saddle else None
+        rhs = np.concatenate([f, g])
+        xin = np.concatenate([np.sin(0.37 * np.arange(n)), 0.5 + np.arange(m)])
+        kw = dict(inner_its=inner, inner_omega=0.8) if inner else {}
+        xo, io = oracle.fgmres(Ao, rhs, B=Bo, pc_type=pc, schur_fact=fact, rtol=1e-9, **kw)
+        y_ref = oracle.apply_K(Ao, Bo, xin) if saddle else oracle.spmv(Ao, xin)
+        got = {}
+        for peer in (0, 1):
+            y = np.zeros(n + m); z = np.zeros(n + m); x = np.zeros(n + m)
+            for r in range(P):
+                k = f"{name}/{peer}/"
+                b, e, its, reason, is_peer, ngh = R[r][k + "meta"]
+                assert is_peer == peer and reason == 2
+                assert np.array_equal(R[r][k + "hist"], R[0][k + "hist"])            # every rank: same branch
+                y[b:e], z[b:e], x[b:e] = R[r][k + "y"][:e - b], R[r][k + "z"][:e - b], R[r][k + "x"][:e - b]
+                if m:
+                    y[n:], z[n:], x[n:] = R[r][k + "y"][-m:], R[r][k + "z"][-m:], R[r][k + "x"][-m:]
+                    assert np.array_equal(R[r][k + "x"][-m:], R[0][k + "x"][-m:])    # multipliers replicated
+            got[peer] = (y, z, x, len(R[0][f"{name}/{peer}/hist"]))
+            assert relerr(y, y_ref) < KERNEL_TOL, (name, peer)
+            assert abs(got[peer][3] - 1 - io["its"]) <= 2, (name, peer)
+            assert relerr(x, xo) < (1e-6 if inner else 1e-7), (name, peer)
+        if P == 2:
+            for a, b_ in zip(got[0][:3], got[1][:3]):
+                assert np.array_equal(a, b_), name
+
+
+def test_peer_store_wait_is_bounded(spk, tmp_path):
+    """A rank that never arrives must turn into SPK_ERR_COMM, not into a kernel that spins for ever:
+    rank 0 multiplies (halo exchange + all-reduce) while rank 1 stays away."""
+    import json
+    _launch_peer_worker(tmp_path, 2, "timeout", 29659, {"SPK_PEER_TIMEOUT_MS": "300"}, timeout=120)
+    d = json.load(open(tmp_path / "rank0.json"))
+    assert d["code"] == -4 and "timed out" in d["msg"]
+
+
+def test_peer_store_needs_one_process_per_rank(spk):
+    """Logical ranks of ONE process are refused (the null stream and hipFree couple their streams):
+    the staged local backend stays in place and says why."""
+    import threading
+    grp = spk.LocalGroup(2)
+    got = [None, None]
+
+    def work(r):
+        c = spk.Context(0)
+        c.comm_init_local(grp, r)
+        got[r] = (c.comm_enable_peer(), c.comm_backend(), c.last_error())
+        c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    grp.close()
+    for on, backend, why in got:
+        assert not on and backend == "local" and "one process per rank" in why
+
+
+def test_peer_store_can_be_switched_off(spk, monkeypatch):
+    import threading
+    monkeypatch.setenv("SPK_COMM_PEER", "0")
+    grp = spk.LocalGroup(2)
+    got = [None, None]
+
+    def work(r):
+        c = spk.Context(0)
+        c.comm_init_local(grp, r)
+        got[r] = (c.comm_enable_peer(), c.comm_backend())
+        c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    grp.close()
+    assert got == [(False, "local"), (False, "local")]
+
+
 def test_row_partitioned_fp32_inner_solve(spk, oracle):
     """The FP32 inner sweeps across 2 logical ranks (single-precision halo staged as doubles): the
     preconditioner must be the same operator as on one rank up to float rounding (the off-rank
@@ -735,3 +845,13 @@ def test_bench_multi_process_flow_over_gloo(spk):
     assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["steps"] == 45 and d2["scaling"] == "strong"
     assert d2["residual_after_steps"] == pytest.approx(d1["residual_after_steps"], rel=1e-6)
     assert d2["roofline"]["bytes_per_launch"] < d1["roofline"]["bytes_per_launch"]        # half the rows per rank
+    # the two processes map each other's windows through HIP IPC: collectives by the solver's own kernels
+    assert d2["config"]["collectives"] == "peer-store"
+    env4 = dict(env, SPK_BENCH_PEER="0")
+    off = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(root, "bench.py"),
+                          "--gpus", "2"] + common, capture_output=True, text=True, timeout=280, cwd=root, env=env4)
+    assert off.returncode == 0, off.stderr[-2000:]
+    d3 = last_json(off.stdout)
+    assert d3["config"]["collectives"] == "host-callback"
+    assert d3["residual_after_steps"] == d2["residual_after_steps"]      # same sums, same order, same bits
