@@ -338,6 +338,8 @@ public:
     {
         const char *t = getenv("SPK_PEER_TIMEOUT_MS");
         timeout_ms_ = t ? (uint32_t)std::max(1, atoi(t)) : 30000u;
+        const char *fz = getenv("SPK_PEER_FUSE");  // 0: all-reduces as launches of their own (A/B runs)
+        fuse_ = !(fz && !strcmp(fz, "0"));
         err_.alloc(4);
         std::memset(ar_map_, 0, sizeof ar_map_);
         std::memset(halo_map_, 0, sizeof halo_map_);
@@ -447,7 +449,40 @@ public:
                 }
             }
         }
-        halo_ok_ = agree(ok);
+        ok = agree(ok);
+        if (ok) {
+            // self-test through both staging parities: element j of the segment rank p sends me must
+            // arrive as p * 2^20 + j (+ 0.5 in the second round)
+            halo_ok_ = true;
+            const int64_t ns = send_off.back(), nr = recv_off.back();
+            DevBuf<double> sb, rb;
+            sb.alloc((size_t)std::max<int64_t>(ns, 1));
+            rb.alloc((size_t)std::max<int64_t>(nr, 1));
+            hipStream_t ts = nullptr;
+            SPK_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+            const uint32_t keep = timeout_ms_;
+            timeout_ms_ = 5000;
+            for (int round = 0; round < 2 && ok; ++round) {
+                std::vector<double> hs((size_t)std::max<int64_t>(ns, 1)), hr((size_t)std::max<int64_t>(nr, 1), -1.0);
+                for (size_t i = 0; i < peers.size(); ++i)
+                    for (int64_t j = send_off[i]; j < send_off[i + 1]; ++j)
+                        hs[(size_t)j] = (double)me_ * 1048576.0 + (double)(j - send_off[i]) + 0.5 * round;
+                SPK_HIP(hipMemcpy(sb.p, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
+                SPK_HIP(hipMemcpy(rb.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice));
+                exchange(sb.p, peers, send_off, rb.p, recv_off, ts);
+                SPK_HIP(hipStreamSynchronize(ts));
+                SPK_HIP(hipMemcpy(hr.data(), rb.p, hr.size() * sizeof(double), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < peers.size() && ok; ++i)
+                    for (int64_t j = recv_off[i]; j < recv_off[i + 1] && ok; ++j)
+                        ok = hr[(size_t)j] == (double)peers[i] * 1048576.0 + (double)(j - recv_off[i]) + 0.5 * round;
+                if (error_word()) ok = false;
+            }
+            timeout_ms_ = keep;
+            (void)hipStreamDestroy(ts);
+            ok = agree(ok);
+            if (!ok) SPK_HIP(hipMemset(err_.p, 0, sizeof(int32_t)));  // the fallback starts clean
+        }
+        halo_ok_ = ok;
     }
     void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                   double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override

@@ -236,6 +236,7 @@ struct Finish {
     double *partials;
     unsigned *counter;
     double *out;
+    PeerAR ar;  // P != 0 (mdot, maxpy only): the finishing workgroup also sums over the ranks
 };
 
 // off-rank part folded into the SpMV epilogue (rowptr over ALL local rows; nullptr: none)
@@ -400,7 +401,8 @@ struct spk_ctx {
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd
     spk::DevBuf<double> small;     // reduced scalars (256 doubles)
     spk::DevBuf<unsigned> counters; // arrival counters of the last-workgroup finish
-    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, counters.p, out}; }
+    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, counters.p, out, spk::k::PeerAR{}}; }
+    spk::k::Finish fin(double *out, const spk::k::PeerAR &ar) { return spk::k::Finish{partials.p, counters.p, out, ar}; }
     spk::DevBuf<double> y1tmp, ttmp;
 
     // Krylov workspace (sized by restart)

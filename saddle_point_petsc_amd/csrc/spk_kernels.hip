@@ -141,6 +141,78 @@ __device__ __forceinline__ void reset_counter(unsigned *counter)
 }
 
 // ---------------------------------------------------------------------------
+// Peer-store collectives over xGMI (replace MPI_Allreduce / VecScatter inside
+// KSPSolve; SURVEY 8(e): the payloads are <= 64 doubles and one node line, so
+// latency is everything).  Data travels as 8-byte GRANULES {sequence number,
+// 32 payload bits} written by ONE system-scope store each into the receiver's
+// window (uncached device memory mapped into every peer): a granule is its own
+// arrival flag, so there is no fence and no second round trip -- the receiver
+// spins on the tag of each granule it needs.  Every poll is bounded (the peer
+// may have died): on time-out the error word is raised and the kernel ends.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// waits until the granule at p carries `seq`; lo = its payload.  false: timed out, or an earlier
+// wait of this context did (the error word is sticky: once a peer is lost every later wait gives up
+// at once, so a whole enqueued restart cycle drains in one time-out, not one per collective).
+__device__ __forceinline__ bool granule_wait(const unsigned long long *p, uint32_t seq, uint32_t timeout_ms, uint32_t &lo,
+                                             const int32_t *err)
+{
+    unsigned long long g = ld_sys(p);
+    if ((uint32_t)(g >> 32) != seq) {
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        for (;;) {
+            __builtin_amdgcn_s_sleep(2);
+            g = ld_sys(p);
+            if ((uint32_t)(g >> 32) == seq) break;
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                wall_clock64() - t0 > (unsigned long long)timeout_ms * 100000ull) {
+                lo = 0;
+                return false;
+            }
+        }
+    }
+    lo = (uint32_t)g;
+    return true;
+}
+__device__ __forceinline__ double join_halves(uint32_t lo, uint32_t hi)
+{
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Threads 0 .. 2*count-1 of the calling workgroup (count <= 64; a double's two halves sit in
+// adjacent lanes) sum vals[0..count) over the ranks into out[0..count): every rank adds the
+// P contributions in rank order, its own included, so all ranks hold the same bits.
+// No barrier inside; vals may be LDS or global, out may alias vals.
+__device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const double *vals, int count, double *out)
+{
+    const int t = threadIdx.x;
+    if (t >= 2 * count) return;
+    const int slot = (int)(a.seq & (kArSlots - 1));
+    const uint32_t half = reinterpret_cast<const uint32_t *>(vals)[t];
+    const unsigned long long g = ((unsigned long long)a.seq << 32) | half;
+    const size_t mine = ((size_t)slot * a.P + a.me) * kArGranules + t;
+    for (int p = 0; p < a.P; ++p) st_sys(a.win[p] + mine, g);
+    const unsigned long long *own = a.win[a.me] + (size_t)slot * a.P * kArGranules + t;
+    double sum = 0.0;
+    bool ok = true;
+    for (int p = 0; p < a.P; ++p) {
+        uint32_t lo;
+        ok = granule_wait(own + (size_t)p * kArGranules, a.seq, a.timeout_ms, lo, a.err) && ok;
+        const uint32_t other = __shfl_xor(lo, 1, kWave);
+        sum += join_halves(lo, other);  // meaningful in even lanes
+    }
+    if (!(t & 1)) out[t >> 1] = sum;
+    if (!ok) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------
 // CSR stream SpMV (A block).  One workgroup = one row tile whose non-zeros
 // (<= 4096) are streamed with 16-byte loads, multiplied by gathered x and
 // staged in LDS; then one thread per row adds its products in CSR order --
@@ -507,7 +579,7 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                                                  const double *__restrict__ w, int64_t n2,
                                                  int64_t n_dot, double *__restrict__ partials,
                                                  int with_ww, unsigned *__restrict__ counter,
-                                                 double *__restrict__ out,
+                                                 double *__restrict__ out, PeerAR ar,
                                                  const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -581,7 +653,9 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
     if (!arrive_last(counter, gridDim.x, &last)) return;
     const int k = nv + (with_ww ? 1 : 0);
     final_reduce(partials, gridDim.x, kPartialLd, k, lds);
-    if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
+    // across ranks: the workgroup that finished this rank's sums also exchanges them (no launch of its own)
+    if (ar.P) peer_allreduce_block(ar, lds, k, out);
+    else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
     reset_counter(counter);
 }
 
@@ -614,10 +688,10 @@ static int vec_grid(int64_t n2, int T = kVT)
 template <int T, int U>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *V2, int nv1,
                         const double *w, int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo,
-                        const int32_t *done)
+                        const PeerAR &ar, const int32_t *done)
 {
 #define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
-                                         n2, n_dot, pp, last, cn, oo, done)
+                                         n2, n_dot, pp, last, cn, oo, ar, done)
     switch (ng) {
     case 1: SPK_MDOT(1); break;
     case 2: SPK_MDOT(2); break;
@@ -634,6 +708,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
     // nv vectors from V, then nv2 from V2 (same stride); results in that order, w.w last
     const int ntot = nv + nv2;
     if (ntot > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: %d vectors exceed %d", ntot, kMaxNv - 1);
+    if (f.ar.P && ntot > 40) fail(SPK_ERR_ARG, "mdot: the all-reduce rides in one launch only (<= 40 vectors)");
     const int64_t n2 = (n + 1) / 2;
     const VecShape vs = vec_shape(n2);
     // up to 40 vectors per launch; w.w is produced by the last launch
@@ -649,10 +724,10 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         double *oo = f.out + v0;
         unsigned *cn = f.counter;
         const int ng = (cnt + 7) / 8 > 0 ? (cnt + 7) / 8 : 1;
-        if (vs.T == 512) mdot_launch<512, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
-        else if (vs.U == 4) mdot_launch<256, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
-        else if (vs.U == 2) mdot_launch<256, 2>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
-        else mdot_launch<256, 1>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, done);
+        if (vs.T == 512) mdot_launch<512, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
+        else if (vs.U == 4) mdot_launch<256, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
+        else if (vs.U == 2) mdot_launch<256, 2>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
+        else mdot_launch<256, 1>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
         v0 += 40;
     } while (v0 < ntot);
 }
@@ -672,7 +747,7 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          double *__restrict__ out,
                                                          const double *__restrict__ bd, int64_t ldb,
                                                          int64_t n_bd, int m, double *__restrict__ w1side,
-                                                         PythArgs py, const int32_t *__restrict__ done)
+                                                         PythArgs py, PeerAR ar, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     if (nv_dev) nv = *nv_dev;
@@ -797,7 +872,8 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
     if (!arrive_last(counter, gridDim.x, &last)) return;
     const int k = 1 + (MP > 0 ? m : 0);
     final_reduce(partials, gridDim.x, kPartialLd, k, red);
-    if ((int)threadIdx.x < k) out[threadIdx.x] = red[threadIdx.x];
+    if (ar.P) peer_allreduce_block(ar, red, k, out);
+    else if ((int)threadIdx.x < k) out[threadIdx.x] = red[threadIdx.x];
     reset_counter(counter);
 }
 
@@ -808,7 +884,7 @@ static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64
                          const int32_t *done)
 {
 #define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, 4, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, py, done)
+                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
     else SPK_MAXPY(0);
@@ -934,77 +1010,8 @@ void gather(const double *x, const int32_t *idx, int64_t n, double *out, const i
 }
 
 // ---------------------------------------------------------------------------
-// Peer-store collectives over xGMI (replace MPI_Allreduce / VecScatter inside
-// KSPSolve; SURVEY 8(e): the payloads are <= 64 doubles and one node line, so
-// latency is everything).  Data travels as 8-byte GRANULES {sequence number,
-// 32 payload bits} written by ONE system-scope store each into the receiver's
-// window (uncached device memory mapped into every peer): a granule is its own
-// arrival flag, so there is no fence and no second round trip -- the receiver
-// spins on the tag of each granule it needs.  Every poll is bounded (the peer
-// may have died): on time-out the error word is raised and the kernel ends.
+// peer-store collectives: stand-alone launches (primitives: top of this file)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// waits until the granule at p carries `seq`; lo = its payload.  false: timed out, or an earlier
-// wait of this context did (the error word is sticky: once a peer is lost every later wait gives up
-// at once, so a whole enqueued restart cycle drains in one time-out, not one per collective).
-__device__ __forceinline__ bool granule_wait(const unsigned long long *p, uint32_t seq, uint32_t timeout_ms, uint32_t &lo,
-                                             const int32_t *err)
-{
-    unsigned long long g = ld_sys(p);
-    if ((uint32_t)(g >> 32) != seq) {
-        const unsigned long long t0 = wall_clock64();  // 100 MHz
-        for (;;) {
-            __builtin_amdgcn_s_sleep(2);
-            g = ld_sys(p);
-            if ((uint32_t)(g >> 32) == seq) break;
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                wall_clock64() - t0 > (unsigned long long)timeout_ms * 100000ull) {
-                lo = 0;
-                return false;
-            }
-        }
-    }
-    lo = (uint32_t)g;
-    return true;
-}
-__device__ __forceinline__ double join_halves(uint32_t lo, uint32_t hi)
-{
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// Threads 0 .. 2*count-1 of the calling workgroup (count <= 64; a double's two halves sit in
-// adjacent lanes) sum vals[0..count) over the ranks into out[0..count): every rank adds the
-// P contributions in rank order, its own included, so all ranks hold the same bits.
-// No barrier inside; vals may be LDS or global, out may alias vals.
-__device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const double *vals, int count, double *out)
-{
-    const int t = threadIdx.x;
-    if (t >= 2 * count) return;
-    const int slot = (int)(a.seq & (kArSlots - 1));
-    const uint32_t half = reinterpret_cast<const uint32_t *>(vals)[t];
-    const unsigned long long g = ((unsigned long long)a.seq << 32) | half;
-    const size_t mine = ((size_t)slot * a.P + a.me) * kArGranules + t;
-    for (int p = 0; p < a.P; ++p) st_sys(a.win[p] + mine, g);
-    const unsigned long long *own = a.win[a.me] + (size_t)slot * a.P * kArGranules + t;
-    double sum = 0.0;
-    bool ok = true;
-    for (int p = 0; p < a.P; ++p) {
-        uint32_t lo;
-        ok = granule_wait(own + (size_t)p * kArGranules, a.seq, a.timeout_ms, lo, a.err) && ok;
-        const uint32_t other = __shfl_xor(lo, 1, kWave);
-        sum += join_halves(lo, other);  // meaningful in even lanes
-    }
-    if (!(t & 1)) out[t >> 1] = sum;
-    if (!ok) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __global__ __launch_bounds__(2 * 64) void peer_allreduce_kernel(PeerAR a, double *buf, int count)
 {
     peer_allreduce_block(a, buf, count, buf);

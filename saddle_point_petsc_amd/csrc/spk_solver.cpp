@@ -623,18 +623,22 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 }
                 c->comm->allreduce_sum(nb, nn, s);
             } else if (single) {
-                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s, c->bd.p, m);
-                c->comm->allreduce_sum(db, loc + 2 + m, s);
+                const k::PeerAR ar = loc + 1 + m <= 40 ? c->comm->fused_allreduce(loc + 2 + m) : k::PeerAR{};
+                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, c->bd.p, m);
+                if (!ar.P) c->comm->allreduce_sum(db, loc + 2 + m, s);
                 k::PythArgs py{m, db, c->ka.tb, nb};
                 k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nullptr), done, s, nullptr, ld, nl, m,
                          w1side, &py);
             } else {
                 // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
-                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s);
-                c->comm->allreduce_sum(db, loc + 2, s);
-                k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nb), done, s, bdp, ld, nl, m,
+                // across ranks the all-reduces ride in the finish of the two kernels (peer-store backend)
+                const k::PeerAR ar1 = loc + 1 <= 40 ? c->comm->fused_allreduce(loc + 2) : k::PeerAR{};
+                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar1), done, s);
+                if (!ar1.P) c->comm->allreduce_sum(db, loc + 2, s);
+                const k::PeerAR ar2 = c->comm->fused_allreduce(nn);
+                k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nb, ar2), done, s, bdp, ld, nl, m,
                          fused ? w1side : nullptr);
-                c->comm->allreduce_sum(nb, nn, s);
+                if (!ar2.P) c->comm->allreduce_sum(nb, nn, s);
                 if (o.cgs_refine != SPK_REFINE_NEVER) {
                     // second pass on the device's own decision (-ksp_gmres_cgs_refinement_type)
                     const int32_t *skip = &c->kst.p->skip_refine;
