@@ -508,6 +508,24 @@ public:
         h.err = err_.p;
         k::peer_exchange(h, sendbuf, recvbuf, s);
     }
+    bool fused_halo(k::SendRanges &sr, double *xghost) override
+    {
+        if (!fuse_ || !halo_ok_ || sr.n != (int)halo_peers_.size() || sr.n < 1) return false;
+        for (int i = 0; i < sr.n; ++i)
+            if (sr.len[i] != halo_send_off_[(size_t)i + 1] - halo_send_off_[(size_t)i]) return false;
+        sr.peer = 1;
+        sr.seq = ++halo_seq_;
+        sr.timeout_ms = timeout_ms_;
+        const int par = (int)(sr.seq & 1u);
+        for (int i = 0; i < sr.n; ++i)
+            sr.remote[i] = halo_map_[halo_peers_[(size_t)i]] +
+                           2 * ((size_t)par * (size_t)halo_remote_ng_[i] + (size_t)halo_remote_off_[i]);
+        sr.mine = halo_own_ + 2 * (size_t)par * (size_t)n_ghost_;
+        sr.nrecv = n_ghost_;
+        sr.xghost = xghost;
+        sr.err = err_.p;
+        return true;
+    }
     void check(hipStream_t s) override
     {
         (void)s;

@@ -111,6 +111,7 @@ struct WideDev {
 // peer-store windows (one-shot collectives over xGMI, spk_comm.cpp / spk_kernels.hip)
 // ---------------------------------------------------------------------------
 namespace k {
+struct SendRanges;
 constexpr int kPeerMax = 8;        // ranks of one node
 constexpr int kArSlots = 4;        // all-reduce slots in flight (a rank is never more than one ahead)
 constexpr int kArGranules = 128;   // 8-byte {seq, half} granules per rank and slot = 64 doubles
@@ -151,6 +152,10 @@ public:
     // window set for the next all-reduce of `count` values, or P == 0 when the backend cannot
     // (the caller then calls allreduce_sum after the kernel)
     virtual k::PeerAR fused_allreduce(int count) { (void)count; return k::PeerAR{}; }
+    // halo exchange performed INSIDE the kernel that produces the vector (contiguous send ranges
+    // only): fills the peer fields of sr for the next exchange and returns true, or returns false
+    // (the caller then calls exchange())
+    virtual bool fused_halo(k::SendRanges &sr, double *xghost) { (void)sr; (void)xghost; return false; }
     // throws SPK_ERR_COMM when a device-side wait of this backend has timed out (call after a sync)
     virtual void check(hipStream_t s) { (void)s; }
     virtual const char *name() const { return "self"; }
@@ -250,6 +255,16 @@ struct SendRanges {
     int n;  // 0: none
     int32_t r0[4], len[4], off[4];
     double *buf;
+    // peer-store backend (Comm::fused_halo): the rows go as granules straight into the neighbours'
+    // staging instead of buf, and extra workgroups at the end of the grid wait for MY ghost rows and
+    // unpack them into xghost -- the halo exchange costs no launch of its own
+    int peer;  // 0: off
+    uint32_t seq, timeout_ms;
+    unsigned long long *remote[4];
+    const unsigned long long *mine;
+    int32_t nrecv;
+    double *xghost;
+    int32_t *err;
 };
 
 // y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
@@ -421,7 +436,7 @@ struct spk_ctx {
 
 namespace spk {
 // solver pieces used by the API layer (spk_solver.cpp)
-void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done);
+void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool halo_done = false);
 void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done);
 void pc_setup(spk_ctx *c, int pc_type, int schur_fact);
 void fgmres(spk_ctx *c, const double *b_dev, double *x_dev, const spk_opts &o, spk_result *res,

@@ -162,7 +162,7 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p
 // wait of this context did (the error word is sticky: once a peer is lost every later wait gives up
 // at once, so a whole enqueued restart cycle drains in one time-out, not one per collective).
 __device__ __forceinline__ bool granule_wait(const unsigned long long *p, uint32_t seq, uint32_t timeout_ms, uint32_t &lo,
-                                             const int32_t *err)
+                                             const int32_t *err, const int32_t *done = nullptr)
 {
     unsigned long long g = ld_sys(p);
     if ((uint32_t)(g >> 32) != seq) {
@@ -175,6 +175,12 @@ __device__ __forceinline__ bool granule_wait(const unsigned long long *p, uint32
                 wall_clock64() - t0 > (unsigned long long)timeout_ms * 100000ull) {
                 lo = 0;
                 return false;
+            }
+            // the solve converged while this kernel was in flight: the peers stop sending, nobody
+            // reads what is missing (every consumer starts with "if (*done) return")
+            if (done && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                lo = 0;
+                return true;
             }
         }
     }
@@ -1633,7 +1639,24 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
     }
 
     const int64_t n2 = nl / 2;  // nl is even on this path (checked by the host)
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+    // peer-store halo: workgroups past the main grid wait for this rank's ghost rows (sent by the
+    // neighbours' head kernels) and unpack them for the SpMV that follows
+    const int gmain = sr.peer ? (int)gridDim.x - (2 * sr.nrecv + kThreads - 1) / kThreads : (int)gridDim.x;
+    if ((int)blockIdx.x >= gmain) {
+        const int64_t g = (int64_t)(blockIdx.x - gmain) * kThreads + threadIdx.x;
+        if (g < 2 * (int64_t)sr.nrecv) {
+            uint32_t lo;
+            const bool ok = granule_wait(sr.mine + g, sr.seq, sr.timeout_ms, lo, sr.err, done);
+            const uint32_t other = __shfl_xor(lo, 1, kWave);
+            if (!(g & 1)) sr.xghost[g >> 1] = join_halves(lo, other);
+            if (!ok) __hip_atomic_store(sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // with a halo to send the grid is walked from both ends inwards, so that the rows the two slab
+    // neighbours wait for leave first
+    const int bx = sr.peer ? ((blockIdx.x & 1) ? gmain - 1 - (int)(blockIdx.x >> 1) : (int)(blockIdx.x >> 1)) : (int)blockIdx.x;
+    for (int64_t i = (int64_t)bx * kThreads + threadIdx.x; i < n2; i += (int64_t)gmain * kThreads) {
         double2 w = reinterpret_cast<double2 *>(v)[i];
         const double2 d = reinterpret_cast<const double2 *>(dinv)[i];
         w.x *= inv_tt;
@@ -1661,11 +1684,26 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
             cc.y = s1 / d.y;
             reinterpret_cast<double2 *>(c)[i] = cc;
         }
-        // rows a neighbour needs go straight into the packed halo buffer (no gather launch)
+        // rows a neighbour needs go straight into the packed halo buffer (no gather launch), or,
+        // with the peer-store backend, as granules into the neighbour's own memory
         for (int q = 0; q < sr.n; ++q) {
             const int64_t e = 2 * i - sr.r0[q];
-            if (e >= 0 && e < sr.len[q]) sr.buf[sr.off[q] + e] = zz.x;
-            if (e + 1 >= 0 && e + 1 < sr.len[q]) sr.buf[sr.off[q] + e + 1] = zz.y;
+            if (sr.peer) {
+                const unsigned long long tag = (unsigned long long)sr.seq << 32;
+                if (e >= 0 && e < sr.len[q]) {
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(zz.x);
+                    st_sys(sr.remote[q] + 2 * e, tag | (b & 0xffffffffull));
+                    st_sys(sr.remote[q] + 2 * e + 1, tag | (b >> 32));
+                }
+                if (e + 1 >= 0 && e + 1 < sr.len[q]) {
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(zz.y);
+                    st_sys(sr.remote[q] + 2 * e + 2, tag | (b & 0xffffffffull));
+                    st_sys(sr.remote[q] + 2 * e + 3, tag | (b >> 32));
+                }
+            } else {
+                if (e >= 0 && e < sr.len[q]) sr.buf[sr.off[q] + e] = zz.x;
+                if (e + 1 >= 0 && e + 1 < sr.len[q]) sr.buf[sr.off[q] + e + 1] = zz.y;
+            }
         }
     }
 }
@@ -1675,9 +1713,11 @@ void fused_head(double *v, const double *nrm, const double *w1raw, const double 
                 const SendRanges *srp)
 {
     const int64_t n2 = nl / 2;
-    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
+    int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
+    if (grid < 1) grid = 1;
     SendRanges sr{};
     if (srp) sr = *srp;
+    if (sr.peer) grid += (2 * sr.nrecv + kThreads - 1) / kThreads;  // the waiting workgroups come last
     if (m <= 4)
         hipLaunchKernelGGL(fused_head_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
                            shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, done);

@@ -310,11 +310,11 @@ void set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, in
 // ---------------------------------------------------------------------------
 // y = K x   (MatMult_Nest over MatMult_MPIAIJ blocks)
 // ---------------------------------------------------------------------------
-void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done)
+void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool halo_done)
 {
     hipStream_t s = c->stream;
     const int32_t nl = c->n_local, m = c->m;
-    if (!c->peers.empty()) {  // a rank may have rows to send without needing any itself
+    if (!c->peers.empty() && !halo_done) {  // a rank may have rows to send without needing any itself
         k::gather(x, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
         c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
     }
@@ -590,24 +590,28 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             if (fused) {
                 // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part);
                 // workgroup 0 also runs the Givens step of iteration loc-1
-                const bool packed = c->send_ranges.n > 0;   // head fills the halo buffer itself
+                k::SendRanges sr = c->send_ranges;
+                const bool packed = sr.n > 0;   // head fills the halo buffer itself ...
+                const bool inhead = packed && c->comm->fused_halo(sr, c->xghost.p);   // ... or does the whole exchange
                 k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
                               c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
-                              packed ? &c->send_ranges : nullptr);
+                              packed ? &sr : nullptr);
                 last = loc;
                 // w += A z0 (halo exchange, then diagonal and off-rank columns in ONE kernel)
                 const k::OffDiag od = c->offdiag();
-                if (!c->peers.empty()) {
+                if (!c->peers.empty() && !inhead) {
                     if (!packed) k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
                 }
                 if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
                 else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
             } else if (fusedj) {
+                k::SendRanges sr = c->send_ranges;
+                const bool inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
                 k::fused_head(Vj(loc), nrmbuf(loc + 1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER,
-                              nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s);
+                              nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s, inhead ? &sr : nullptr);
                 last = loc;
-                op_mult(c, Zj(loc), w, done);            // w = A z_j (halo inside)
+                op_mult(c, Zj(loc), w, done, inhead);    // w = A z_j (halo inside, unless the head kernel did it)
             } else {
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
