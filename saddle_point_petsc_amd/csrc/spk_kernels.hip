@@ -90,14 +90,31 @@ __device__ __forceinline__ double peek(const double *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// true in every thread of the workgroup that arrived last (nblocks arrivals expected)
+// true in every thread of the workgroup that arrived last (nblocks arrivals expected).
+// Two levels: workgroup b first arrives at sub-counter b % 8 (a line of its own; b, b+8, ... are the
+// workgroups that share an XCD), the last one of each residue class arrives at the top counter.
+// Same-address atomics are served one after the other (~12 ns each): a burst of 256..1024
+// workgroups finishing together queues 32..128 deep on eight lines instead of 256..1024 deep on
+// one.  Causality: publish -> drain -> sub-counter add -> (last of the class) top add -> the
+// reader's sc1 loads, every step an agent-scope atomic whose returned value proves the previous one.
+constexpr int kCounterStride = 32;  // unsigned per line of 128 B; counters[0] = top, [(1+g)*32] = class g
 __device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned nblocks, int *flag_lds)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag_lds = (old == nblocks - 1);
+        int last = 0;
+        const unsigned g = blockIdx.x & 7u;
+        const unsigned in_class = (nblocks + 7u - g) / 8u;          // workgroups b < nblocks with b % 8 == g
+        unsigned *sub = counter + (1 + g) * kCounterStride;
+        unsigned old = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == in_class - 1) {
+            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            const unsigned classes = nblocks < 8u ? nblocks : 8u;
+            old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (old == classes - 1);
+        }
+        *flag_lds = last;
     }
     __syncthreads();
     return *flag_lds != 0;
@@ -665,22 +682,142 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
     reset_counter(counter);
 }
 
+// ---------------------------------------------------------------------------
+// Small vectors -- a rank's slab of a strong-scaling run (262 k rows at 1024^2 / 8), the 256^2 and
+// 512^2 grids.  Such a vector gives every wave of the chip ONE tile: the kernels above then walk
+// their j+1 basis vectors group after group, a chain of dependent memory round trips with nothing
+// else resident to hide them (measured on the 1/8 slab: 13.7 / 25.6 us for 15 / 30 vectors,
+// 2.5 TB/s out of the Infinity Cache).  The "wave-split" MDOT below turns the work by 90 degrees:
+// the four waves of a workgroup share one LONG tile (64 lanes x U double2 = up to 8 KB per
+// vector) and split the VECTORS between them, so a wave's chain is a quarter as long, its
+// accumulators and shuffles a quarter as many, and every stream is read in 8 KB runs.
+// Wave q owns vectors [q*per, (q+1)*per): its sums go straight to the partials.  Measured on the
+// 1/8 slab: 11.0 / 17.6 us for 15 / 30 vectors (slope 0.33 us = 6.3 TB/s per vector).  The same turn
+// applied to MAXPY (contributions combined through LDS) gained nothing; MAXPY instead runs thin
+// workgroups with 8 vectors in flight there (vec_shape).
+// Sums are formed in a fixed order: reproducible, not bit-equal to the streaming form.
+// ---------------------------------------------------------------------------
+template <int VW, int U, int G, bool NT>
+__global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__ V, int64_t ldv, int nv,
+                                                      const double *__restrict__ V2, int nv1,
+                                                      const double *__restrict__ w, int64_t n2, int64_t n_dot,
+                                                      double *__restrict__ partials, int with_ww,
+                                                      unsigned *__restrict__ counter, double *__restrict__ out,
+                                                      PeerAR ar, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double lds[256];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (nv + 3) >> 2;
+    const int v0 = wave * per;
+    const int cnt = (nv - v0) < per ? (nv - v0) : per;  // may be <= 0: a wave without vectors
+    double acc[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[i] = 0.0;
+    double ww = 0.0;
+    for (int64_t tile = blockIdx.x; tile * (64 * U) < n2; tile += gridDim.x) {
+        double2 wv[U];
+        int64_t idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = tile * (64 * U) + u * 64 + lane;
+            if (idx[u] < n2) {
+                wv[u] = ld2(w, idx[u]);
+                if (2 * idx[u] >= n_dot) wv[u].x = 0.0;
+                if (2 * idx[u] + 1 >= n_dot) wv[u].y = 0.0;
+            } else {
+                wv[u].x = wv[u].y = 0.0;
+                idx[u] = 0;
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ww += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
+        }
+#pragma unroll
+        for (int g0 = 0; g0 < VW; g0 += G) {
+            if (g0 < cnt) {  // wave-uniform
+                double2 a[G][U];
+#pragma unroll
+                for (int v = 0; v < G; ++v) {
+                    const bool live = g0 + v < cnt;
+                    const int ic = v0 + (live ? g0 + v : 0);
+                    const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(ic - nv1) * ldv);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, live ? idx[u] : 0);
+                }
+#pragma unroll
+                for (int v = 0; v < G; ++v) {
+                    const double mk = (g0 + v < cnt) ? 1.0 : 0.0;
+                    double d = 0.0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                    acc[g0 + v] += mk * d;
+                }
+            }
+        }
+    }
+    double *row = partials + (size_t)blockIdx.x * kPartialLd;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        if (i < cnt) {  // wave-uniform
+            const double s = wave_sum(acc[i]);
+            if (lane == 0) publish(row + v0 + i, s);
+        }
+    }
+    if (wave == 0 && with_ww) {
+        const double s = wave_sum(ww);
+        if (lane == 0) publish(row + nv, s);
+    }
+    if (!arrive_last(counter, gridDim.x, &last)) return;
+    const int k = nv + (with_ww ? 1 : 0);
+    final_reduce(partials, gridDim.x, kPartialLd, k, lds);
+    if (ar.P) peer_allreduce_block(ar, lds, k, out);
+    else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
+    reset_counter(counter);
+}
+
+// tile length (double2 per lane) and grid of the wave-split forms: about one tile per workgroup
+struct WsShape {
+    int U, grid;
+    bool on;
+};
+static WsShape ws_shape(int64_t n2)
+{
+    WsShape v;
+    static const int knob = [] { const char *e = getenv("SPK_VEC_WS"); return e ? atoi(e) : -1; }();  // 0: off, 2/4/8: force U
+    v.on = n2 < (int64_t)kVecMaxBlocks * 2048 && knob != 0;
+    v.U = n2 >= (int64_t)kVecMaxBlocks * 64 * 8 ? 8 : (n2 >= (int64_t)kVecMaxBlocks * 64 * 4 ? 4 : 2);
+    if (knob == 2 || knob == 4 || knob == 8) v.U = knob;
+    int64_t tiles = (n2 + 64 * v.U - 1) / (64 * v.U);
+    if (tiles < 1) tiles = 1;
+    v.grid = (int)(tiles < kVecMaxBlocks ? tiles : kVecMaxBlocks);
+    return v;
+}
+
 // Workgroup shape of the reducing vector kernels: big vectors get 512 threads x 4 double2
 // (few fat workgroups: cheap finish), small ones get thinner tiles so that ~256 workgroups
 // still exist (a 131 k-row slab on 32 workgroups left 7/8 of the chip idle: 20 us instead of 5).
 struct VecShape {
-    int T, U, grid;
+    int T, U, grid, G;
 };
-static VecShape vec_shape(int64_t n2)
+static VecShape vec_shape(int64_t n2, bool maxpy = false)
 {
     VecShape v;
+    v.G = 4;
+    int cap = kVecMaxBlocks;
     if (n2 >= (int64_t)kVecMaxBlocks * 2048) { v.T = 512; v.U = 4; }
     else if (n2 >= (int64_t)kVecMaxBlocks * 1024) { v.T = 256; v.U = 4; }
     else if (n2 >= (int64_t)kVecMaxBlocks * 512) { v.T = 256; v.U = 2; }
     else { v.T = 256; v.U = 1; }
+    // MAXPY on small vectors: thin workgroups, 8 vectors in flight (1/8 slab, 30 vectors: 17.1 -> 12.7 us,
+    // 1/4 slab: 84 -> 79 us per iteration; the two-level arrival makes 512 workgroups affordable)
+    if (maxpy && n2 < (int64_t)kVecMaxBlocks * 1024) { v.T = 256; v.U = 1; v.G = 8; cap = 1024; }
+    else if (maxpy && n2 < (int64_t)kVecMaxBlocks * 2048) { v.T = 256; v.U = 2; v.G = 8; cap = 1024; }
     int64_t tiles = (n2 + (int64_t)v.T * v.U - 1) / ((int64_t)v.T * v.U);
     if (tiles < 1) tiles = 1;
-    v.grid = (int)(tiles < kVecMaxBlocks ? tiles : kVecMaxBlocks);
+    v.grid = (int)(tiles < cap ? tiles : cap);
     return v;
 }
 static int vec_grid(int64_t n2, int T = kVT)
@@ -691,12 +828,12 @@ static int vec_grid(int64_t n2, int T = kVT)
     return (int)(tiles < cap ? tiles : cap);
 }
 
-template <int T, int U>
+template <int T, int U, int G>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *V2, int nv1,
                         const double *w, int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo,
                         const PeerAR &ar, const int32_t *done)
 {
-#define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, 4, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
+#define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, G, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
                                          n2, n_dot, pp, last, cn, oo, ar, done)
     switch (ng) {
     case 1: SPK_MDOT(1); break;
@@ -730,10 +867,28 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         double *oo = f.out + v0;
         unsigned *cn = f.counter;
         const int ng = (cnt + 7) / 8 > 0 ? (cnt + 7) / 8 : 1;
-        if (vs.T == 512) mdot_launch<512, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
-        else if (vs.U == 4) mdot_launch<256, 4>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
-        else if (vs.U == 2) mdot_launch<256, 2>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
-        else mdot_launch<256, 1>(ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done);
+        const WsShape ws = ws_shape(n2);
+        if (ws.on) {
+#define SPK_MDOT_WS(VW, UU, GG) hipLaunchKernelGGL((mdot_ws_kernel<VW, UU, GG, true>), dim3(ws.grid), dim3(256), 0, s, Vp, ldv, cnt, \
+                                                   V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done)
+#define SPK_MDOT_WS_U(VW) do { if (ws.U == 8) SPK_MDOT_WS(VW, 8, 2); else if (ws.U == 4) SPK_MDOT_WS(VW, 4, 4); else SPK_MDOT_WS(VW, 2, 4); } while (0)
+            const int per = (cnt + 3) / 4;
+            if (per <= 4) SPK_MDOT_WS_U(4);
+            else if (per <= 8) SPK_MDOT_WS_U(8);
+            else SPK_MDOT_WS_U(12);
+#undef SPK_MDOT_WS_U
+#undef SPK_MDOT_WS
+            v0 += 40;
+            continue;
+        }
+#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done
+        if (vs.T == 512) mdot_launch<512, 4, 4>(SPK_MDOT_ARGS);
+        else if (vs.U == 4) mdot_launch<256, 4, 4>(SPK_MDOT_ARGS);
+        else if (vs.U == 2 && vs.G == 8) mdot_launch<256, 2, 8>(SPK_MDOT_ARGS);
+        else if (vs.U == 2) mdot_launch<256, 2, 4>(SPK_MDOT_ARGS);
+        else if (vs.G == 8) mdot_launch<256, 1, 8>(SPK_MDOT_ARGS);
+        else mdot_launch<256, 1, 4>(SPK_MDOT_ARGS);
+#undef SPK_MDOT_ARGS
         v0 += 40;
     } while (v0 < ntot);
 }
@@ -883,13 +1038,13 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
     reset_counter(counter);
 }
 
-template <int T, int U>
+template <int T, int U, int G>
 static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64_t ldv, int nv, const int32_t *nv_dev,
                          const double *a, double sign, double *w, int64_t n2, int64_t n_dot, const Finish &f,
                          const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side, const PythArgs &py,
                          const int32_t *done)
 {
-#define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, 4, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
+#define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, G, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
                                           sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
@@ -903,16 +1058,20 @@ void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const do
            const PythArgs *pyth)
 {
     const int64_t n2 = (n + 1) / 2;
-    const VecShape vs = vec_shape(n2);
+    const VecShape vs = vec_shape(n2, true);
     PythArgs py{};
     py.m = -1;
     if (pyth) py = *pyth;
     // MP > 0 also switches on the lambda side copy; in single-reduction mode bd is not read
     const int mp = ((bd || pyth) && m > 0) ? (m <= 4 ? 4 : 8) : 0;
-    if (vs.T == 512) maxpy_launch<512, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
-    else if (vs.U == 4) maxpy_launch<256, 4>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
-    else if (vs.U == 2) maxpy_launch<256, 2>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
-    else maxpy_launch<256, 1>(mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done);
+#define SPK_MAXPY_ARGS mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done
+    if (vs.T == 512) maxpy_launch<512, 4, 4>(SPK_MAXPY_ARGS);
+    else if (vs.U == 4) maxpy_launch<256, 4, 4>(SPK_MAXPY_ARGS);
+    else if (vs.U == 2 && vs.G == 8) maxpy_launch<256, 2, 8>(SPK_MAXPY_ARGS);
+    else if (vs.U == 2) maxpy_launch<256, 2, 4>(SPK_MAXPY_ARGS);
+    else if (vs.G == 8) maxpy_launch<256, 1, 8>(SPK_MAXPY_ARGS);
+    else maxpy_launch<256, 1, 4>(SPK_MAXPY_ARGS);
+#undef SPK_MAXPY_ARGS
 }
 
 // ---------------------------------------------------------------------------
