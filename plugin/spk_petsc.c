@@ -110,6 +110,9 @@ static PetscErrorCode SpkGlueCreate(MPI_Comm comm, Mat A, Mat B, SpkGlue **out)
         if (!rank && spk_comm_unique_id(id)) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "libspk: %s", spk_last_error(NULL));
         ierr = MPI_Bcast(id, 128, MPI_BYTE, 0, comm); CHKERRQ(ierr);
         SPK_CHK(g->ctx, spk_comm_init_rccl(g->ctx, rank, size, id));
+        /* Krylov all-reduces and halo rows written by the solver's kernels into the peers' HBM
+         * over xGMI; stays on RCCL (collectively) when a rank cannot map a peer's window */
+        SPK_CHK(g->ctx, spk_comm_enable_peer(g->ctx, NULL));
     }
     ierr = MatGetOwnershipRange(A, &rstart, &rend); CHKERRQ(ierr);
     ierr = MatGetSize(A, &N, NULL); CHKERRQ(ierr);

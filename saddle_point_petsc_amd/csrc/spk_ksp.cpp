@@ -111,7 +111,9 @@ int SpkKSPSetCommRCCL(SpkKSP k, int rank, int nranks, const void *id128)
 {
     if (!k) return SPK_ERR_ARG;
     if (const int rc = ensure_ctx(k)) return rc;
-    return from_ctx(k, spk_comm_init_rccl(k->ctx, rank, nranks, id128));
+    if (const int rc = spk_comm_init_rccl(k->ctx, rank, nranks, id128)) return from_ctx(k, rc);
+    // peer-store collectives on top (falls back to RCCL collectively; see include/spk.h)
+    return from_ctx(k, spk_comm_enable_peer(k->ctx, nullptr));
 }
 
 int SpkKSPSetOperators(SpkKSP k, const SpkMatCSR *A, const SpkMatCSR *B)
