@@ -227,7 +227,7 @@ int spk_kernel_maxpy(spk_ctx *ctx, int64_t n, int32_t nv, const double *a, const
  * x is a deterministic fill sin(0.37 i). */
 int spk_time_spmv(spk_ctx *ctx, int warmup, int reps, double *ms_per_launch);
 /* Generic form for the other kernels of an iteration (tuning / profiles):
- * which = "spmv" | "spmv_bcsr" | "spmv_acc" | "mult" | "pc" | "mdot" | "maxpy" | "scale" | "wide_dot" |
+ * which = "spmv" | "spmv_bcsr" | "spmv_acc" | "mult" | "pc" | "mdot" | "maxpy" | "maxpy_nonorm" | "scale" | "wide_dot" |
  * "bt_update"; nv = vectors for mdot/maxpy.  Needs operators (and pc_setup for
  * "pc"); allocates its own scratch vectors. */
 int spk_time_kernel(spk_ctx *ctx, const char *which, int nv, int warmup, int reps,

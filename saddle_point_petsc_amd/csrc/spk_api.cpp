@@ -435,6 +435,7 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
         else if (w == "pc") { if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "pc not set up"); spk::op_pc_apply(c, x, y, nullptr); }
         else if (w == "mdot") spk::k::mdot(V.p, ld, nv, x, N, N, c->fin(c->small.p), nullptr, s);
         else if (w == "maxpy") spk::k::maxpy(V.p, ld, nv, nullptr, coef.p, -1.0, x, N, N, c->fin(c->small.p + 64), nullptr, s);
+        else if (w == "maxpy_nonorm") spk::k::maxpy(V.p, ld, nv, nullptr, coef.p, -1.0, x, N, N, c->fin(nullptr), nullptr, s);
         else if (w == "scale") spk::k::scale_dev(x, N, coef.p, nullptr, s);
         else if (w == "wide_dot") { if (!c->have_B) spk::fail(SPK_ERR_STATE, "no B"); spk::k::wide_dot(c->B, x, c->fin(c->small.p), nullptr, s); }
         else if (w == "bt_update") { if (!c->have_B || !c->pc_ready) spk::fail(SPK_ERR_STATE, "no B / pc"); spk::k::bt_update(1, c->Bt, c->dinv.p, x, c->small.p + 200, y, nullptr, s); }

@@ -234,12 +234,13 @@ constexpr int kPartialLd = 64;   // leading dimension of block partials
 constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
 
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row);
+// arms the block-partials buffer of the cross-workgroup finish (spk_kernels.hip)
+void arm_partials(double *p, size_t n, hipStream_t s);
 
-// where a reducing kernel leaves its result: block partials, the arrival
-// counter of the "last workgroup finishes" protocol, and the output slot
+// where a reducing kernel leaves its result: block partials (armed with the sentinel of the
+// "last block reduces" protocol, spk_kernels.hip) and the output slot
 struct Finish {
     double *partials;
-    unsigned *counter;
     double *out;
     PeerAR ar;  // P != 0 (mdot, maxpy only): the finishing workgroup also sums over the ranks
 };
@@ -415,9 +416,8 @@ struct spk_ctx {
     // scratch
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd
     spk::DevBuf<double> small;     // reduced scalars (256 doubles)
-    spk::DevBuf<unsigned> counters; // arrival counters of the last-workgroup finish
-    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, counters.p, out, spk::k::PeerAR{}}; }
-    spk::k::Finish fin(double *out, const spk::k::PeerAR &ar) { return spk::k::Finish{partials.p, counters.p, out, ar}; }
+    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, out, spk::k::PeerAR{}}; }
+    spk::k::Finish fin(double *out, const spk::k::PeerAR &ar) { return spk::k::Finish{partials.p, out, ar}; }
     spk::DevBuf<double> y1tmp, ttmp;
 
     // Krylov workspace (sized by restart)

@@ -25,9 +25,8 @@ namespace k {
 
 constexpr int kThreads = 256;
 constexpr int kWave = 64;
-// Reducing vector kernels run 1024-thread workgroups on a grid of <= 256 (one per
-// CU): the "last workgroup finishes" protocol costs one same-address atomic per
-// workgroup (~12 ns each, serialised), so few fat workgroups beat many thin ones.
+// Reducing vector kernels on big vectors run fat workgroups on a grid of <= 256 (one per
+// CU): the reducer reads one partial row per workgroup, so few fat workgroups beat many thin ones.
 constexpr int kVT = 1024;
 constexpr int kVWaves = kVT / kWave;
 constexpr int kVecUnroll = 4;    // double2 per thread per vector tile
@@ -72,15 +71,27 @@ __device__ __forceinline__ int4 ld4i(const int32_t *p)
 }
 
 // ---------------------------------------------------------------------------
-// Cross-workgroup finish without a second launch and without fences
-// (cdna_hip_programming.md Guideline 16, form R1 + "the workgroup whose add came
-// last"): every workgroup PUBLISHES its k partial sums with sc1 (write-through)
-// stores, drains them (s_waitcnt vmcnt(0)) and makes ONE agent-scope atomic add;
-// the workgroup whose add returns gridDim-1 re-reads all partials with sc1
-// loads and sums them in a FIXED order (bitwise reproducible, no float atomics).
-// The counter is reset by that workgroup, so the next launch on the stream
-// finds it at zero.
+// Cross-workgroup finish without a second launch, without fences and without
+// counters.  Every slot of the partials buffer rests at a SENTINEL (a NaN bit
+// pattern no arithmetic produces).  Every workgroup PUBLISHES its k partial
+// sums with sc1 (write-through) 8-byte stores and is done -- no drain, no
+// arrival.  The workgroup with the highest block index (dispatched last) is the
+// reducer: it reads all partials with sc1 loads, spinning on any slot that still
+// holds the sentinel, puts the sentinel back, and sums in a FIXED order (bitwise
+// reproducible, no float atomics).  A value is its own arrival flag, so the chain
+// after the last producer is one store flight + one load round trip, where
+// "drain -> atomic arrival -> re-read" (cdna_hip_programming.md Guideline 16, R1)
+// was three to four dependent round trips: measured on a 262 k-row vector, MAXPY +
+// norm 7.3 -> 5.8 us, MDOT 7.8 -> 6.4 us (3.4 us for the MAXPY stream without any reduction).
+// The reducer asks for kFinBatch partials per thread at a time and simply asks again while any
+// of them is still armed; a per-slot re-poll, or 32 at a time, doubled the VGPRs of the WHOLE
+// kernel (75 -> 149..256) and cost more occupancy in the streaming part than the finish gained.
+// The sentinel is restored inside the kernel that consumed it, so the next launch
+// on the stream (ordered by the kernel boundary) finds every slot armed.
+// Every spin is bounded; a slot that never arrives reads as NaN
+// (-> KSP_DIVERGED_NANORINF), it cannot hang the kernel.
 // ---------------------------------------------------------------------------
+constexpr unsigned long long kSentinelBits = 0xFFF8DEADBEEF5A5Aull;
 __device__ __forceinline__ void publish(double *p, double v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -89,59 +100,56 @@ __device__ __forceinline__ double peek(const double *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// true in every thread of the workgroup that arrived last (nblocks arrivals expected).
-// Two levels: workgroup b first arrives at sub-counter b % 8 (a line of its own; b, b+8, ... are the
-// workgroups that share an XCD), the last one of each residue class arrives at the top counter.
-// Same-address atomics are served one after the other (~12 ns each): a burst of 256..1024
-// workgroups finishing together queues 32..128 deep on eight lines instead of 256..1024 deep on
-// one.  Causality: publish -> drain -> sub-counter add -> (last of the class) top add -> the
-// reader's sc1 loads, every step an agent-scope atomic whose returned value proves the previous one.
-constexpr int kCounterStride = 32;  // unsigned per line of 128 B; counters[0] = top, [(1+g)*32] = class g
-__device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned nblocks, int *flag_lds)
+__device__ __forceinline__ bool is_sentinel(double v)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int last = 0;
-        const unsigned g = blockIdx.x & 7u;
-        const unsigned in_class = (nblocks + 7u - g) / 8u;          // workgroups b < nblocks with b % 8 == g
-        unsigned *sub = counter + (1 + g) * kCounterStride;
-        unsigned old = __hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == in_class - 1) {
-            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            const unsigned classes = nblocks < 8u ? nblocks : 8u;
-            old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (old == classes - 1);
-        }
-        *flag_lds = last;
-    }
-    __syncthreads();
-    return *flag_lds != 0;
+    return (unsigned long long)__double_as_longlong(v) == kSentinelBits;
 }
 
-// last workgroup (blockDim.x = T threads, power of two): scratch[i] = sum_b partials[b*ld + i],
-// i < k <= 64.  Strided slices (loads issued in batches of 8 before the adds), then a fixed
-// binary tree; the result is valid in LDS scratch[0..k) after return.  scratch: T doubles.
-__device__ __forceinline__ void final_reduce(const double *partials, int nb, int ld, int k, double *scratch)
+// true in every thread of the reducing workgroup (the last block of the grid)
+__device__ __forceinline__ bool arrive_last(unsigned nblocks)
+{
+    if (blockIdx.x != nblocks - 1) return false;
+    __syncthreads();  // the caller's LDS staging is reused as scratch below
+    return true;
+}
+
+// reducer (blockDim.x = T threads, power of two): scratch[i] = sum_b partials[b*ld + i], i < k <= 64.
+// Strided slices (a thread's loads are all requested before its first add: one memory round trip
+// when everything has arrived), then a fixed binary tree; the result is valid in LDS scratch[0..k)
+// after return.  scratch: T doubles.
+constexpr int kFinBatch = 16;  // partials a reducer thread requests together (registers of the WHOLE kernel: 32 cost 2x the VGPRs)
+__device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, int k, double *scratch)
 {
     const int T = blockDim.x;
     int kk = 1;
     while (kk < k) kk <<= 1;
     const int i = threadIdx.x & (kk - 1), sl = threadIdx.x / kk, nsl = T / kk;
+    const double armed = __longlong_as_double((long long)kSentinelBits);
     double acc = 0.0;
     if (i < k) {
-        // all of a thread's partials are requested before the first add: one memory round trip
-        // (each is an sc1 load that misses L2) instead of one per batch
-        for (int b0 = sl; b0 < nb; b0 += nsl * 32) {
-            double v[32];
+        for (int b0 = sl; b0 < nb; b0 += nsl * kFinBatch) {
+            double v[kFinBatch];
+            // the whole batch is requested at once (one round trip) and simply requested again while
+            // any of its slots is still armed, i.e. its workgroup has not published yet
+            const unsigned long long t0 = wall_clock64();
+            bool armed_seen;
+            do {
+                armed_seen = false;
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
+                for (int u = 0; u < kFinBatch; ++u) {
+                    const int b = b0 + u * nsl;
+                    v[u] = b < nb ? peek(partials + (size_t)b * ld + i) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < kFinBatch; ++u) armed_seen = armed_seen || is_sentinel(v[u]);
+                if (armed_seen) __builtin_amdgcn_s_sleep(1);
+            } while (armed_seen && wall_clock64() - t0 < 400000000ull);  // 4 s at 100 MHz
+#pragma unroll
+            for (int u = 0; u < kFinBatch; ++u) {
                 const int b = b0 + u * nsl;
-                v[u] = b < nb ? peek(partials + (size_t)b * ld + i) : 0.0;
+                if (b < nb) publish(partials + (size_t)b * ld + i, armed);  // re-arm for the next launch
+                acc += v[u];
             }
-#pragma unroll
-            for (int u = 0; u < 32; ++u) acc += v[u];
         }
     }
     scratch[sl * kk + i] = acc;
@@ -152,9 +160,15 @@ __device__ __forceinline__ void final_reduce(const double *partials, int nb, int
     }
 }
 
-__device__ __forceinline__ void reset_counter(unsigned *counter)
+// fills the partials buffer with the sentinel (once, at allocation)
+__global__ void arm_partials_kernel(double *p, size_t n)
 {
-    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = __longlong_as_double((long long)kSentinelBits);
+}
+void arm_partials(double *p, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(arm_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
 }
 
 // ---------------------------------------------------------------------------
@@ -525,12 +539,11 @@ void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, doubl
 __global__ __launch_bounds__(kVT) void wide_dot_kernel(
     const int32_t *__restrict__ colidx, const double *__restrict__ val,
     const int32_t *__restrict__ winptr, int m, int nwin, const double *__restrict__ x,
-    const double *__restrict__ scale, double *__restrict__ partials, unsigned *__restrict__ counter,
+    const double *__restrict__ scale, double *__restrict__ partials,
     double *__restrict__ out, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     __shared__ double scratch[kVT];
-    __shared__ int last;
     const int w = blockIdx.x;
     for (int r = 0; r < m; ++r) {
         const int k0 = winptr[w * m + r], k1 = winptr[(w + 1) * m + r];
@@ -560,10 +573,9 @@ __global__ __launch_bounds__(kVT) void wide_dot_kernel(
         }
         __syncthreads();
     }
-    if (!arrive_last(counter, gridDim.x, &last)) return;
+    if (!arrive_last(gridDim.x)) return;
     final_reduce(partials, nwin, kPartialLd, m, scratch);
     if ((int)threadIdx.x < m) out[threadIdx.x] = scratch[threadIdx.x];
-    reset_counter(counter);
 }
 
 static void wide_dot_scaled(const WideDev &B, const double *x, const double *scale, const Finish &f,
@@ -571,7 +583,7 @@ static void wide_dot_scaled(const WideDev &B, const double *x, const double *sca
 {
     if (B.nwin == 0) return;
     hipLaunchKernelGGL(wide_dot_kernel, dim3(B.nwin), dim3(kVT), 0, s, B.colidx.p, B.val.p,
-                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.counter, f.out, done);
+                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.out, done);
 }
 void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s)
 {
@@ -601,14 +613,13 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                                                  const double *__restrict__ V2, int nv1,
                                                  const double *__restrict__ w, int64_t n2,
                                                  int64_t n_dot, double *__restrict__ partials,
-                                                 int with_ww, unsigned *__restrict__ counter,
+                                                 int with_ww,
                                                  double *__restrict__ out, PeerAR ar,
                                                  const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     constexpr int NA = NG * 8 + 1, W = T / kWave, TILE2 = T * U;
     __shared__ double lds[(W * NA > T) ? W * NA : T];
-    __shared__ int last;
     double acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.0;
@@ -673,13 +684,12 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
         if (i < nv) publish(row + i, s);
         else if (i == NA - 1 && with_ww) publish(row + nv, s);
     }
-    if (!arrive_last(counter, gridDim.x, &last)) return;
+    if (!arrive_last(gridDim.x)) return;
     const int k = nv + (with_ww ? 1 : 0);
     final_reduce(partials, gridDim.x, kPartialLd, k, lds);
     // across ranks: the workgroup that finished this rank's sums also exchanges them (no launch of its own)
     if (ar.P) peer_allreduce_block(ar, lds, k, out);
     else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
-    reset_counter(counter);
 }
 
 // ---------------------------------------------------------------------------
@@ -701,13 +711,11 @@ template <int VW, int U, int G, bool NT>
 __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__ V, int64_t ldv, int nv,
                                                       const double *__restrict__ V2, int nv1,
                                                       const double *__restrict__ w, int64_t n2, int64_t n_dot,
-                                                      double *__restrict__ partials, int with_ww,
-                                                      unsigned *__restrict__ counter, double *__restrict__ out,
+                                                      double *__restrict__ partials, int with_ww, double *__restrict__ out,
                                                       PeerAR ar, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     __shared__ double lds[256];
-    __shared__ int last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = (nv + 3) >> 2;
     const int v0 = wave * per;
@@ -770,12 +778,11 @@ __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__
         const double s = wave_sum(ww);
         if (lane == 0) publish(row + nv, s);
     }
-    if (!arrive_last(counter, gridDim.x, &last)) return;
+    if (!arrive_last(gridDim.x)) return;
     const int k = nv + (with_ww ? 1 : 0);
     final_reduce(partials, gridDim.x, kPartialLd, k, lds);
     if (ar.P) peer_allreduce_block(ar, lds, k, out);
     else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
-    reset_counter(counter);
 }
 
 // tile length (double2 per lane) and grid of the wave-split forms: about one tile per workgroup
@@ -830,11 +837,11 @@ static int vec_grid(int64_t n2, int T = kVT)
 
 template <int T, int U, int G>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *V2, int nv1,
-                        const double *w, int64_t n2, int64_t n_dot, double *pp, int last, unsigned *cn, double *oo,
+                        const double *w, int64_t n2, int64_t n_dot, double *pp, int last, double *oo,
                         const PeerAR &ar, const int32_t *done)
 {
 #define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, G, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
-                                         n2, n_dot, pp, last, cn, oo, ar, done)
+                                         n2, n_dot, pp, last, oo, ar, done)
     switch (ng) {
     case 1: SPK_MDOT(1); break;
     case 2: SPK_MDOT(2); break;
@@ -865,12 +872,11 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         const double *V2p = nv1 > 0 ? V2 : V2 + (size_t)(v0 - nv) * ldv;
         double *pp = f.partials + v0;
         double *oo = f.out + v0;
-        unsigned *cn = f.counter;
         const int ng = (cnt + 7) / 8 > 0 ? (cnt + 7) / 8 : 1;
         const WsShape ws = ws_shape(n2);
         if (ws.on) {
 #define SPK_MDOT_WS(VW, UU, GG) hipLaunchKernelGGL((mdot_ws_kernel<VW, UU, GG, true>), dim3(ws.grid), dim3(256), 0, s, Vp, ldv, cnt, \
-                                                   V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done)
+                                                   V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, done)
 #define SPK_MDOT_WS_U(VW) do { if (ws.U == 8) SPK_MDOT_WS(VW, 8, 2); else if (ws.U == 4) SPK_MDOT_WS(VW, 4, 4); else SPK_MDOT_WS(VW, 2, 4); } while (0)
             const int per = (cnt + 3) / 4;
             if (per <= 4) SPK_MDOT_WS_U(4);
@@ -881,7 +887,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
             v0 += 40;
             continue;
         }
-#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, cn, oo, f.ar, done
+#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, done
         if (vs.T == 512) mdot_launch<512, 4, 4>(SPK_MDOT_ARGS);
         else if (vs.U == 4) mdot_launch<256, 4, 4>(SPK_MDOT_ARGS);
         else if (vs.U == 2 && vs.G == 8) mdot_launch<256, 2, 8>(SPK_MDOT_ARGS);
@@ -904,7 +910,6 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          const double *__restrict__ a, double sign,
                                                          double *__restrict__ w, int64_t n2,
                                                          int64_t n_dot, double *__restrict__ partials,
-                                                         unsigned *__restrict__ counter,
                                                          double *__restrict__ out,
                                                          const double *__restrict__ bd, int64_t ldb,
                                                          int64_t n_bd, int m, double *__restrict__ w1side,
@@ -941,7 +946,6 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
         }
     }
     __shared__ double red[(W * NR > T) ? W * NR : T];
-    __shared__ int last;
     double nrm = 0.0;
     double tacc[MP > 0 ? MP : 1];
 #pragma unroll
@@ -1030,12 +1034,11 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
         for (int j = 0; j < W; ++j) t += red[j * NR + threadIdx.x];
         if ((int)threadIdx.x <= m) publish(partials + (size_t)blockIdx.x * kPartialLd + threadIdx.x, t);
     }
-    if (!arrive_last(counter, gridDim.x, &last)) return;
+    if (!arrive_last(gridDim.x)) return;
     const int k = 1 + (MP > 0 ? m : 0);
     final_reduce(partials, gridDim.x, kPartialLd, k, red);
     if (ar.P) peer_allreduce_block(ar, red, k, out);
     else if ((int)threadIdx.x < k) out[threadIdx.x] = red[threadIdx.x];
-    reset_counter(counter);
 }
 
 template <int T, int U, int G>
@@ -1045,7 +1048,7 @@ static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64
                          const int32_t *done)
 {
 #define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, G, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          sign, w, n2, n_dot, f.partials, f.counter, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, done)
+                                          sign, w, n2, n_dot, f.partials, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
     else SPK_MAXPY(0);
@@ -1125,13 +1128,11 @@ void axpby(double a, const double *x, double b, double *y, int64_t n, const int3
 
 __global__ __launch_bounds__(kVT) void sqnorm_kernel(const double *__restrict__ x, int64_t n2,
                                                           int64_t n_dot, double *__restrict__ partials,
-                                                          unsigned *__restrict__ counter,
                                                           double *__restrict__ out,
                                                           const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     __shared__ double red[kVT];
-    __shared__ int last;
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kVT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVT) {
         const double2 v = reinterpret_cast<const double2 *>(x)[i];
@@ -1147,16 +1148,15 @@ __global__ __launch_bounds__(kVT) void sqnorm_kernel(const double *__restrict__ 
         for (int j = 0; j < kVWaves; ++j) t += red[j];
         publish(partials + (size_t)blockIdx.x * kPartialLd, t);
     }
-    if (!arrive_last(counter, gridDim.x, &last)) return;
+    if (!arrive_last(gridDim.x)) return;
     final_reduce(partials, gridDim.x, kPartialLd, 1, red);
     if (threadIdx.x == 0) out[0] = red[0];
-    reset_counter(counter);
 }
 void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n_dot + 1) / 2;
     const int grid = vec_grid(n2);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.counter, f.out, done);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.out, done);
 }
 
 __global__ __launch_bounds__(kThreads) void gather_kernel(const double *__restrict__ x,
@@ -1516,14 +1516,12 @@ template <int MP>
 __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict__ x, int64_t n2, int64_t n_dot,
                                                         const double *__restrict__ bd, int64_t ldb, int64_t n_bd,
                                                         int m, double *__restrict__ w1side,
-                                                        double *__restrict__ partials,
-                                                        unsigned *__restrict__ counter, double *__restrict__ out,
+                                                        double *__restrict__ partials, double *__restrict__ out,
                                                         const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     constexpr int T = 512, NR = MP + 1, W = T / kWave;
     __shared__ double red[(W * NR > T) ? W * NR : T];
-    __shared__ int last;
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
@@ -1558,10 +1556,9 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
         for (int j = 0; j < W; ++j) t += red[j * NR + threadIdx.x];
         if ((int)threadIdx.x <= m) publish(partials + (size_t)blockIdx.x * kPartialLd + threadIdx.x, t);
     }
-    if (!arrive_last(counter, gridDim.x, &last)) return;
+    if (!arrive_last(gridDim.x)) return;
     final_reduce(partials, gridDim.x, kPartialLd, 1 + m, red);
     if ((int)threadIdx.x < 1 + m) out[threadIdx.x] = red[threadIdx.x];
-    reset_counter(counter);
 }
 void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
                double *w1side, const Finish &f, const int32_t *done, hipStream_t s)
@@ -1569,9 +1566,9 @@ void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int6
     const int64_t n2 = (n + 1) / 2;
     const int grid = vec_grid(n2, 512);
     if (m <= 4)
-        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.counter, f.out, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, done);
     else
-        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.counter, f.out, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, done);
 }
 
 __global__ void sum_slots_kernel(const double *__restrict__ slots, int nslots, int ld, int count,

@@ -25,9 +25,12 @@ using namespace spk;
 
 void spk_ctx::ensure_scratch()
 {
-    if (!partials.p) partials.alloc((size_t)k::kMaxBlocks * k::kPartialLd);
+    if (!partials.p) {
+        partials.alloc((size_t)k::kMaxBlocks * k::kPartialLd);
+        k::arm_partials(partials.p, partials.n, stream);
+        SPK_HIP(hipStreamSynchronize(stream));
+    }
     if (!small.p) small.alloc(512);
-    if (!counters.p) counters.alloc(9 * 32);  // top + 8 class counters, a 128-byte line each
     if (!y1tmp.p) y1tmp.alloc(64);
     if (!ttmp.p) ttmp.alloc(64);
 }

@@ -27,7 +27,7 @@ model = {"spmv": 12 * nnz + 4 * n + 2 * vec, "spmv_bcsr": 12 * nnz + 4 * n + 2 *
          "bt_update": 12 * nnzB + 4 * n + 3 * vec, "scale": 2 * vec}
 out = {}
 for k in a.kernels.split(","):
-    if k in ("mdot", "maxpy"):
+    if k in ("mdot", "maxpy", "maxpy_nonorm"):
         for nv in [int(v) for v in a.nvs.split(",")]:
             ms = c.time_kernel(k, nv, 10, a.reps)
             b = (nv + 1) * vec if k == "mdot" else (nv + 2) * vec
