@@ -91,6 +91,8 @@ def main():
                                                                        "shape, --grid nodes per side, dof 3)")
     ap.add_argument("--grid-y", type=int, default=0, help="node lines in y (default: square); e.g. 128 emulates one "
                                                           "rank's slab of the 8-GPU split on one GPU")
+    ap.add_argument("--grid-z", type=int, default=0, help="--dim 3: node planes in z (default: --grid); e.g. --grid 256 --grid-z 32 "
+                                                          "is one rank's z-slab of the 256^3 grid split 8 ways")
     ap.add_argument("--pc", default="schur-full", choices=["schur-full", "schur-lower", "schur-upper", "schur-diag", "jacobi"])
     ap.add_argument("--restart", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,18 +140,19 @@ def main():
 
     M = args.grid
     My = args.grid_y or M
+    Mz = args.grid_z or M
     t_setup = time.time()
     t_asm = time.time()
     asm_threads = max(1, min(16, host_cores() // max(1, world)))   # N ranks share the host: stay far below
     saddle = args.pc != "jacobi"                                   # the box's thread limits
     B = g = None
     if args.dim == 3:
-        n = 3 * M * My * M
-        nnz_global = 9 * (3 * M - 2) * (3 * My - 2) * (3 * M - 2)
-        rb, re_ = S.partition_slab3d(M, My, M, rank, world)
-        A, f = S.AssembleOperator_Laplace3D(M, My, M, rb, re_, nthreads=asm_threads)
+        n = 3 * M * My * Mz
+        nnz_global = 9 * (3 * M - 2) * (3 * My - 2) * (3 * Mz - 2)
+        rb, re_ = S.partition_slab3d(M, My, Mz, rank, world)
+        A, f = S.AssembleOperator_Laplace3D(M, My, Mz, rb, re_, nthreads=asm_threads)
         if saddle:
-            B, g = S.AssembleOperator_Constraints3D(M, My, M, rb, re_)
+            B, g = S.AssembleOperator_Constraints3D(M, My, Mz, rb, re_)
     else:
         n, nnz_global = S.grid_sizes(M, My)
         rb, re_ = S.partition_slab(M, My, rank, world)
@@ -259,7 +262,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": (f"{M}x{My} DMDA node grid, dof 2" if args.dim == 2 else
-                                f"{M}x{My}x{M} node grid (build-defined 3-D generator), dof 3")
+                                f"{M}x{My}x{Mz} node grid (build-defined 3-D generator), dof 3")
                                + f" (n={n}, nnz(A)={nnz_global}), "
                                + (f"saddle K=[A B^T;B 0] with {B.nrows} constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",

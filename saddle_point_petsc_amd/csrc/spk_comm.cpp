@@ -620,6 +620,13 @@ private:
             } else if (w.ok != 1) {
                 good = false;
             } else {
+                // direct access to the peer's device, as RCCL's P2P transport sets it up (harmless when the
+                // peer is not visible under this index or access is already on)
+                int ndev = 0, can = 0;
+                if (w.device != device_ && hipGetDeviceCount(&ndev) == hipSuccess && w.device < ndev &&
+                    hipDeviceCanAccessPeer(&can, device_, w.device) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(w.device, 0);
+                (void)hipGetLastError();
                 void *q = nullptr;
                 if (hipIpcOpenMemHandle(&q, w.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
                     (void)hipGetLastError();
