@@ -1662,7 +1662,7 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t 
 // iteration-head kernel, where it overlaps with that kernel's streaming.
 __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2)
 {
-    __shared__ double Hc[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
+    __shared__ double Hc[kMaxNv + 2], Hr[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
     KrylovState *st = ka.st;
     if (st->done) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
@@ -1689,19 +1689,24 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
     double hapbnd = fabs(tt / rs_loc);
     if (hapbnd > 1e-30) hapbnd = 1e-30;
     const int hapend = !(tt > hapbnd);
-    Hc[loc + 1] = tt;
     st->tt = tt;
     st->inv_tt = hapend ? 1.0 : 1.0 / tt;
-    // previous rotations on the new column
+    // previous rotations on the new column.  The running entry stays in a register and the rotated
+    // entries go to an array of their own, so the loop's LDS loads do not wait for its stores: the
+    // serial chain is two FMAs per step (LDS round trips per step cost ~3 us at loc = 30, on the
+    // critical path of the head kernel this step rides in)
+    double run = Hc[0];
     for (int j = 1; j <= loc; ++j) {
-        const double h0 = Hc[j - 1], h1 = Hc[j];
-        Hc[j - 1] = ccs[j - 1] * h0 + sss[j - 1] * h1;
-        Hc[j] = ccs[j - 1] * h1 - sss[j - 1] * h0;
+        const double h1 = Hc[j], cj = ccs[j - 1], sj = sss[j - 1];
+        Hr[j - 1] = cj * run + sj * h1;
+        run = cj * h1 - sj * run;
     }
+    Hr[loc] = run;
+    Hr[loc + 1] = tt;
     double rnorm;
     int reason = 0;
     if (!hapend) {
-        const double h0 = Hc[loc], h1 = Hc[loc + 1];
+        const double h0 = run, h1 = tt;
         const double d = sqrt(h0 * h0 + h1 * h1);
         if (d == 0.0) {
             st->reason = SPK_DIVERGED_NULL;
@@ -1713,12 +1718,12 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
         ka.ss[loc] = sn;
         ka.rs[loc + 1] = -sn * rs_loc;
         ka.rs[loc] = c * rs_loc;
-        Hc[loc] = c * h0 + sn * h1;
+        Hr[loc] = c * h0 + sn * h1;
         rnorm = fabs(sn * rs_loc);
     } else {
         rnorm = 0.0;
     }
-    for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hc[j];
+    for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hr[j];
     st->its += 1;
     st->loc_done = loc + 1;
     st->rnorm = rnorm;
@@ -1781,6 +1786,9 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
 #pragma unroll
     for (int r = 0; r < MP; ++r) yv[r] = ys[r];
 
+    // workgroup 0 streams nothing: it writes the m multiplier entries and runs the Givens step of
+    // the previous iteration -- a serial chain of a few microseconds that must not sit in front of
+    // rows somebody waits for (the first tile carries the halo rows of the lower neighbour)
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < m) {
             const int r = threadIdx.x;
@@ -1792,14 +1800,16 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
             c[nl + r] = w1;
         }
         if (loc_prev >= 0) givens_block(ka, loc_prev, dots_prev, nrm);
+        return;
     }
+    const int bid = (int)blockIdx.x - 1;
 
     const int64_t n2 = nl / 2;  // nl is even on this path (checked by the host)
     // peer-store halo: workgroups past the main grid wait for this rank's ghost rows (sent by the
     // neighbours' head kernels) and unpack them for the SpMV that follows
-    const int gmain = sr.peer ? (int)gridDim.x - (2 * sr.nrecv + kThreads - 1) / kThreads : (int)gridDim.x;
-    if ((int)blockIdx.x >= gmain) {
-        const int64_t g = (int64_t)(blockIdx.x - gmain) * kThreads + threadIdx.x;
+    const int gmain = (int)gridDim.x - 1 - (sr.peer ? (2 * sr.nrecv + kThreads - 1) / kThreads : 0);
+    if (bid >= gmain) {
+        const int64_t g = (int64_t)(bid - gmain) * kThreads + threadIdx.x;
         if (g < 2 * (int64_t)sr.nrecv) {
             uint32_t lo;
             const bool ok = granule_wait(sr.mine + g, sr.seq, sr.timeout_ms, lo, sr.err, done);
@@ -1811,7 +1821,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
     }
     // with a halo to send the grid is walked from both ends inwards, so that the rows the two slab
     // neighbours wait for leave first
-    const int bx = sr.peer ? ((blockIdx.x & 1) ? gmain - 1 - (int)(blockIdx.x >> 1) : (int)(blockIdx.x >> 1)) : (int)blockIdx.x;
+    const int bx = sr.peer ? ((bid & 1) ? gmain - 1 - (bid >> 1) : (bid >> 1)) : bid;
     for (int64_t i = (int64_t)bx * kThreads + threadIdx.x; i < n2; i += (int64_t)gmain * kThreads) {
         double2 w = reinterpret_cast<double2 *>(v)[i];
         const double2 d = reinterpret_cast<const double2 *>(dinv)[i];
@@ -1873,6 +1883,7 @@ void fused_head(double *v, const double *nrm, const double *w1raw, const double 
     if (grid < 1) grid = 1;
     SendRanges sr{};
     if (srp) sr = *srp;
+    grid += 1;                                                      // workgroup 0: scalars + Givens only
     if (sr.peer) grid += (2 * sr.nrecv + kThreads - 1) / kThreads;  // the waiting workgroups come last
     if (m <= 4)
         hipLaunchKernelGGL(fused_head_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
