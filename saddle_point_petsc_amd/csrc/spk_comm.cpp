@@ -1,15 +1,18 @@
 // spk_comm.cpp -- the two collectives KSPSolve needs across ranks, replacing
 // what PETSc does with MPI inside the call at
 // /root/reference/src/SaddlePointProblem.c:70:
-//   * MPI_Allreduce of <= restart+2 doubles per Krylov reduction (VecMDot,
-//     VecNorm)                       -> ncclAllReduce on the solver's stream
-//   * VecScatter of the ghost entries MatMult_MPIAIJ needs
-//                                    -> grouped ncclSend/ncclRecv with the two
-//                                       slab neighbours over xGMI
+//   * MPI_Allreduce of <= restart+2 doubles per Krylov reduction (VecMDot, VecNorm)
+//   * VecScatter of the ghost entries MatMult_MPIAIJ needs (the two slab neighbours)
 // Backends:
-//   RcclComm   one process per GPU (production; RCCL is dlopen'ed so that the
-//              library loads, and the CPU tests run, on a box without it and so
-//              that the process shares whichever librccl is already mapped)
+//   PeerComm   production: windows of the peers' HBM mapped through HIP IPC, the solver's own
+//              kernels store tagged 8-byte granules into them over xGMI (spk_kernels.hip);
+//              wraps one of the backends below for set-up traffic and as the fallback
+//   RcclComm   one process per GPU: ncclAllReduce / grouped ncclSend+ncclRecv on the solver's
+//              stream, ncclAllGather for set-up (RCCL is dlopen'ed so that the library loads,
+//              and the CPU tests run, on a box without it and so that the process shares
+//              whichever librccl is already mapped)
+//   HostCbComm every operation staged through host callbacks (gloo/MPI): lets N processes
+//              share ONE GPU, which RCCL refuses -- rehearsals on a 1-GPU box
 //   LocalComm  several logical ranks inside one process on ONE device, each
 //              driven by its own host thread -- lets a 1-GPU box run the
 //              partitioned algorithm (parity tests); host barriers, slow.

@@ -5,7 +5,8 @@
 //   spk_solver.cpp   device-resident FGMRES: the host only ENQUEUES a restart
 //                    cycle; Hessenberg/Givens/convergence live on the device
 //   spk_kernels.hip  hand-written gfx950 kernels (HBM-bound, FP64, no MFMA)
-//   spk_comm.cpp     collectives: self / RCCL (one process per GPU) / local
+//   spk_comm.cpp     collectives: peer-store windows over xGMI on top of RCCL (one process per
+//                    GPU); host-callback and in-process backends for 1-GPU rehearsals
 //   spk_partition.cpp host-only row-slab split + halo plan
 #pragma once
 #include <hip/hip_runtime.h>
@@ -275,9 +276,6 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
                const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
-// y[rows[i]] += Ao_row_i . xg   (compressed off-rank block)
-void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
-                  const int32_t *done, hipStream_t s);
 // f.out[r] = B_r . x, r < m
 void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s);
 // same with x replaced by x .* dinv (the B D x0 step of the Schur PC, no stored D x0)

@@ -6,15 +6,16 @@
 //
 // What each kernel replaces inside PETSc (reached from
 // /root/reference/src/SaddlePointProblem.c:70):
-//   spmv_stream_kernel   MatMult_SeqAIJ on the A block (+ MatMultTransposeAdd of B)
-//   spmv_offdiag_kernel  the off-process part of MatMult_MPIAIJ
+//   spmv_bcsr_kernel,    MatMult_SeqAIJ on the A block (+ MatMultTransposeAdd of B), the off-process
+//   spmv_stream_kernel   part of MatMult_MPIAIJ in the epilogue of the same kernel
 //   wide_dot_kernel      MatMult_SeqAIJ on the 4 long rows of B
-//   mdot_kernel          VecMDot (+ the squared norm of w in the same pass)
+//   mdot_kernel, _ws     VecMDot (+ the squared norm of w in the same pass)
 //   maxpy_kernel         VecMAXPY (+ VecNorm of the result in the same pass)
 //   scale/axpby/jacobi   VecScale, VecAXPY/WAXPY, PCApply_Jacobi
 //   bt_update/schur_y1   the block steps of PCApply_FieldSplit_Schur
 //   krylov_*             KSPFGMRESCycle's scalar work: Hessenberg column,
 //                        Givens rotations, convergence test, back substitution
+//   peer_* / granules    MPI_Allreduce and VecScatter across ranks (stores into the peers' HBM)
 #include "spk_internal.hpp"
 
 #include <cmath>
@@ -508,32 +509,10 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
                            bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done);
 }
 
-// compressed off-rank block: few short rows, one thread per row
-__global__ __launch_bounds__(kThreads) void spmv_offdiag_kernel(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
-    const double *__restrict__ val, const int32_t *__restrict__ rows, int nrows,
-    const double *__restrict__ xg, double *__restrict__ y, const int32_t *__restrict__ done)
-{
-    if (done && *done) return;
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= nrows) return;
-    double s = 0.0;
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * xg[colidx[k]];
-    y[rows[i]] += s;
-}
-
-void spmv_offdiag(const CsrDev &Ao, const int32_t *rows, const double *xg, double *y,
-                  const int32_t *done, hipStream_t s)
-{
-    if (Ao.nrows == 0) return;
-    hipLaunchKernelGGL(spmv_offdiag_kernel, dim3((Ao.nrows + kThreads - 1) / kThreads), dim3(kThreads),
-                       0, s, Ao.rowptr.p, Ao.colidx.p, Ao.val.p, rows, Ao.nrows, xg, y, done);
-}
-
 // ---------------------------------------------------------------------------
 // B x for the short-and-wide constraint block (4 rows of ~n/2 entries): one
 // workgroup per (column window, row), 16-byte loads of the row's entries in the
-// window, x (optionally x .* scale) gathered; the last workgroup sums the
+// window, x (optionally x .* scale) gathered; the last block of the grid sums the
 // window partials of each row in window order.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kVT) void wide_dot_kernel(
@@ -819,7 +798,7 @@ static VecShape vec_shape(int64_t n2, bool maxpy = false)
     else if (n2 >= (int64_t)kVecMaxBlocks * 512) { v.T = 256; v.U = 2; }
     else { v.T = 256; v.U = 1; }
     // MAXPY on small vectors: thin workgroups, 8 vectors in flight (1/8 slab, 30 vectors: 17.1 -> 12.7 us,
-    // 1/4 slab: 84 -> 79 us per iteration; the two-level arrival makes 512 workgroups affordable)
+    // 1/4 slab: 84 -> 79 us per iteration)
     if (maxpy && n2 < (int64_t)kVecMaxBlocks * 1024) { v.T = 256; v.U = 1; v.G = 8; cap = 1024; }
     else if (maxpy && n2 < (int64_t)kVecMaxBlocks * 2048) { v.T = 256; v.U = 2; v.G = 8; cap = 1024; }
     int64_t tiles = (n2 + (int64_t)v.T * v.U - 1) / ((int64_t)v.T * v.U);

@@ -727,6 +727,48 @@ def test_peer_store_can_be_switched_off(spk, monkeypatch):
     assert got == [(False, "local"), (False, "local")]
 
 
+def test_one_sided_halo(spk, oracle):
+    """Structurally non-symmetric split: rank 1 needs a column of rank 0, rank 0 needs nothing -- it
+    still has to SEND (its n_ghost is 0; PETSc's VecScatter has the same one-sided shape)."""
+    import threading
+    n, half = 64, 32
+    rp = np.arange(0, 2 * n + 1, 2, dtype=np.int32) - 1
+    rp[0] = 0
+    ci = np.empty(2 * n - 1, np.int32)
+    va = np.empty(2 * n - 1)
+    ci[0], va[0] = 0, 2.0
+    for i in range(1, n):
+        ci[2 * i - 1], va[2 * i - 1] = i - 1, -1.0 - 0.01 * i      # sub-diagonal
+        ci[2 * i], va[2 * i] = i, 2.0 + 0.1 * i
+    A = spk.CSR(rp, ci, va, n)
+    x = _x(n, 5)
+    y_ref = oracle.spmv(oracle.CSR(A.rowptr, A.colidx, A.val, A.ncols), x)
+    grp = spk.LocalGroup(2)
+    out, errs = [None, None], []
+
+    def work(r):
+        try:
+            sl = A.slab(r * half, (r + 1) * half)
+            c = spk.Context(0)
+            c.comm_init_local(grp, r)
+            c.set_block(spk.BLOCK_A00, sl)
+            out[r] = (c.mult(x[r * half:(r + 1) * half]), c.sizes()["n_ghost"])
+            c.close()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            raise
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=200) for t in th]
+    grp.close()
+    assert not errs, errs
+    assert out[0][1] == 0 and out[1][1] == 1
+    y = np.concatenate([out[0][0], out[1][0]])
+    assert np.array_equal(y[:half], y_ref[:half]) and np.array_equal(y[half + 1:], y_ref[half + 1:])   # local rows: bitwise
+    assert relerr(y, y_ref) < KERNEL_TOL      # the boundary row adds its off-rank column last (and fused)
+
+
 def test_row_partitioned_fp32_inner_solve(spk, oracle):
     """The FP32 inner sweeps across 2 logical ranks (single-precision halo staged as doubles): the
     preconditioner must be the same operator as on one rank up to float rounding (the off-rank
