@@ -213,6 +213,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- integrity of the timed solve (every N): the residual norm the device carries through its
+    # Givens recurrence must equal the TRUE residual ||b - K x|| recomputed from the iterate with one
+    # more (collective) product -- a wrong halo or all-reduce cannot satisfy this
+    xh = ctx.vec_get(x_dev, len(rhs))
+    yh = ctx.mult(xh)
+    nl_ = len(f)
+    r2 = float(np.sum((rhs[:nl_] - yh[:nl_]) ** 2)) + (float(np.sum((rhs[nl_:] - yh[nl_:]) ** 2)) if rank == 0 else 0.0)
+    if dist is not None:
+        import torch
+        t = torch.tensor([r2], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        r2 = float(t.item())
+    true_rnorm = float(np.sqrt(r2))
+    residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= 1e-6 * max(true_rnorm, 1e-300))
+
     # ---- the same K iterations with b and x handed over as HOST arrays (what a PCSHELL/KSP glue over
     # host Vecs does): adds one H2D of b and one D2H of x per solve over PCIe.  Reported, never `value`.
     host_rate = None
@@ -275,6 +290,7 @@ def main():
         "spmv_gbps": achieved,
         "spmv_ms": spmv_ms,
         "residual_after_steps": info["rnorm"] / info["rnorm0"] if info["rnorm0"] else None,
+        "residual_check": {"recurrence": info["rnorm"], "true": true_rnorm, "consistent": residual_ok},
         "value_with_host_vectors": host_rate,
         "setup_seconds": t_setup,
         "setup_breakdown": {"host_assembly": t_asm, "set_operators_upload": t_up, "pc_setup": t_pc},
