@@ -343,6 +343,11 @@ public:
         timeout_ms_ = t ? (uint32_t)std::max(1, atoi(t)) : 30000u;
         const char *fz = getenv("SPK_PEER_FUSE");  // 0: all-reduces as launches of their own (A/B runs)
         fuse_ = !(fz && !strcmp(fz, "0"));
+        // Granules are the latency tool: 8-byte stores, twice the bytes.  A halo segment beyond this
+        // many doubles (a node PLANE of a 3-D slab: 1.57 MB at 256^3 against 16 KiB for a node line
+        // at 1024^2) is bandwidth-bound and goes through the inner backend's bulk send/recv instead.
+        const char *hm = getenv("SPK_PEER_HALO_MAX");
+        halo_max_ = hm ? std::max(0, atoi(hm)) : 8192;
         err_.alloc(4);
         std::memset(ar_map_, 0, sizeof ar_map_);
         std::memset(halo_map_, 0, sizeof halo_map_);
@@ -428,8 +433,10 @@ public:
         n_ghost_ = n_ghost;
         std::string why;
         bool ok = peers.size() <= 4;
+        for (size_t i = 0; i < peers.size(); ++i)
+            ok = ok && send_off[i + 1] - send_off[i] <= halo_max_ && recv_off[i + 1] - recv_off[i] <= halo_max_;
         // staging: two parities x n_ghost doubles x two granules
-        const size_t bytes = sizeof(unsigned long long) * 4 * (size_t)std::max<int32_t>(n_ghost, 1);
+        const size_t bytes = sizeof(unsigned long long) * 4 * (size_t)std::max<int32_t>(ok ? n_ghost : 1, 1);
         ok = alloc_window(&halo_own_, bytes, &why) && ok;
         int64_t roff[k::kPeerMax];
         for (int p = 0; p < k::kPeerMax; ++p) roff[p] = -1;
@@ -662,6 +669,7 @@ private:
     std::unique_ptr<Comm> inner_;
     int device_, P_, me_;
     uint32_t timeout_ms_ = 30000, ar_seq_ = 0, halo_seq_ = 0;
+    int halo_max_ = 8192;
     bool fuse_ = true, halo_ok_ = false;
     DevBuf<int32_t> err_;
     unsigned long long *ar_own_ = nullptr, *halo_own_ = nullptr;

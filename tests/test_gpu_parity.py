@@ -107,8 +107,11 @@ def test_schur_diag_known_answer(spk, appendix_b):
 
 
 # --------------------------------------------------------------------------- Gram-Schmidt kernels
-@pytest.mark.parametrize("n,nv", [(1, 1), (7, 3), (2047, 8), (2048, 9), (4099, 17), (100000, 31), (300001, 40), (65536, 0)])
+@pytest.mark.parametrize("n,nv", [(1, 1), (7, 3), (2047, 8), (2048, 9), (4099, 17), (100000, 31), (300001, 40), (65536, 0),
+                                  (140001, 5), (262144, 13), (600000, 22), (1200001, 33)])
 def test_mdot_maxpy(ctx, n, nv):
+    """Every form of the two kernels: wave-split MDOT with 2 / 4 / 8 double2 per lane and 4 / 8 / 12
+    vectors per wave, thin-workgroup MAXPY, the streaming forms of both (>= 1 M entries), ragged tails."""
     rng = np.random.default_rng(n + nv)
     V = rng.standard_normal((max(nv, 1), n))[:nv]
     w = rng.standard_normal(n)
@@ -628,15 +631,18 @@ def _launch_peer_worker(tmp_path, P, mode, port, env_extra=None, timeout=280):
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
 
 
-@pytest.mark.parametrize("P", [2, 3])
-def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P):
+@pytest.mark.parametrize("P,halo_max", [(2, None), (3, None), (2, "100")])
+def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_max):
     """P PROCESSES on this GPU, each owning a row slab; the peer-store backend maps the other
     processes' windows through HIP IPC and the solver's own kernels write the Krylov all-reduces and
     the halo rows into them (tests/_peer_worker.py).  Checked per case: every rank holds the same
     scalars bit for bit (same residual history), the result equals the single-rank oracle to the
     usual bars, and with two ranks -- where the host-staged all-reduce adds in the same order -- it
-    is bit-identical to the host-staged run."""
-    _launch_peer_worker(tmp_path, P, "cases", 29650 + P)
+    is bit-identical to the host-staged run.  halo_max = 100: halo segments beyond 100 doubles take the
+    inner backend's bulk send/recv (what a 3-D node plane does in production) while the all-reduces
+    stay on the windows."""
+    _launch_peer_worker(tmp_path, P, "cases", 29650 + P + (10 if halo_max else 0),
+                        {"SPK_PEER_HALO_MAX": halo_max} if halo_max else None)
     R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
     cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_lower_unfused", 2, (24, 26), oracle.PC_SCHUR, 1, 0),
              ("jacobi", 2, (24, 26), oracle.PC_JACOBI, 0, 0), ("schur_diag_fp32", 2, (24, 26), oracle.PC_SCHUR, 0, 3),
