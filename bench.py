@@ -228,6 +228,27 @@ def main():
     true_rnorm = float(np.sqrt(r2))
     residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= 1e-6 * max(true_rnorm, 1e-300))
 
+    # ---- the opt-in single-reduction mode on the same K iterations (one all-reduce and three launches
+    # per iteration instead of two and four; ||w'||^2 by Pythagoras, see include/spk.h).  Reported
+    # beside `value`, never as `value`: PETSc's default Gram-Schmidt makes two reductions.
+    single_mode = None
+    if saddle and args.pc in ("schur-full", "schur-lower") and args.inner_sweeps == 0 and args.single_reduce == 0:
+        kws = dict(kw, single_reduce=1)
+        ctx.fgmres_device(b_dev, x_dev, max_it=min(args.warmup, 30) or 1, **kws)
+        barrier()
+        t0s = time.perf_counter()
+        infos = ctx.fgmres_device(b_dev, x_dev, max_it=args.steps, **kws)
+        barrier()
+        es = time.perf_counter() - t0s
+        if dist is not None:
+            import torch
+            t = torch.tensor([es], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            es = float(t.item())
+        single_mode = {"value": args.steps / es, "ms_per_step": es / args.steps * 1e3,
+                       "residual_after_steps": infos["rnorm"] / infos["rnorm0"] if infos["rnorm0"] else None,
+                       "reductions_per_iteration": 1, "launches_per_iteration": 3}
+
     # ---- the same K iterations with b and x handed over as HOST arrays (what a PCSHELL/KSP glue over
     # host Vecs does): adds one H2D of b and one D2H of x per solve over PCIe.  Reported, never `value`.
     host_rate = None
@@ -292,6 +313,7 @@ def main():
         "residual_after_steps": info["rnorm"] / info["rnorm0"] if info["rnorm0"] else None,
         "residual_check": {"recurrence": info["rnorm"], "true": true_rnorm, "consistent": residual_ok},
         "value_with_host_vectors": host_rate,
+        "single_reduction_mode": single_mode,
         "setup_seconds": t_setup,
         "setup_breakdown": {"host_assembly": t_asm, "set_operators_upload": t_up, "pc_setup": t_pc},
         # achieved = ALGORITHMIC (CSR) bytes / time.  When the kernel streams the

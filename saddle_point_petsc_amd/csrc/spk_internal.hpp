@@ -356,6 +356,12 @@ void fused_head(double *v, const double *nrm, const double *w1raw, const double 
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
                 const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
                 const SendRanges *sr = nullptr);
+// single-reduction mode: MAXPY of iteration loc + head of iteration loc+1 + Givens of iteration loc
+// in one pass (dots = reduced [h, B D w, w.w]; tb = B D v_i per basis vector, (restart+2) x 8)
+void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double *tb, double *nrm_out, double *w,
+                const double *dinv, const double *bd, int64_t ldb, const double *shat, const double *gram, int fact,
+                int64_t nl, int m, double *z, double *c, double *w1side, const double *wl_in, double *wl_out,
+                const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *sr = nullptr);
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)

@@ -1872,6 +1872,226 @@ void fused_head(double *v, const double *nrm, const double *w1raw, const double 
                            shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, done);
 }
 
+// ---------------------------------------------------------------------------
+// Single-reduction iteration, second half and first half of the next one in ONE pass
+// (opts.single_reduce = 1, fused Schur path): with h = V^T w, q = B D w and w.w already
+// reduced over the ranks, everything the head of iteration loc+1 needs is known before
+// the update of iteration loc starts:
+//   ||w'||^2 = w.w - |h|^2,  B D w' = q - sum h_i (B D v_i),  lambda part of w' (m entries,
+//   recomputed by every workgroup from the m entries of the basis vectors)
+// so MAXPY (w' = w - V h), VecScale (v = w'/||w'||), PCApply_FieldSplit_Schur (z) and the
+// B^T part of the next operator product (c) stream the vector once, and the Givens step of
+// iteration loc runs in workgroup 0 of the same launch.  An iteration is then three launches
+// (this, SpMV, MDot) with one reduction.  Same arithmetic per entry as maxpy_kernel followed by
+// fused_head_kernel.
+// ---------------------------------------------------------------------------
+template <int T, int G, int U, int MP>
+__global__ __launch_bounds__(T) void maxpy_head_kernel(
+    const double *__restrict__ V, int64_t ldv, int nv, const double *__restrict__ dots, double *__restrict__ tb,
+    double *__restrict__ nrm_out, double *__restrict__ w, const double *__restrict__ dinv,
+    const double *__restrict__ bd, int64_t ldb, const double *__restrict__ shat, const double *__restrict__ gram,
+    int fact, int64_t nl, int m, double *__restrict__ z, double *__restrict__ c, double *__restrict__ w1side,
+    const double *__restrict__ wl_in, double *__restrict__ wl_out, KrylovArrays ka, int loc, SendRanges sr,
+    const int32_t *__restrict__ done)
+{
+    // wl_in: the m lambda entries of w (= what the previous head wrote into c[nl..]; the SpMV does not
+    // touch them) as a side copy -- workgroup 0 overwrites w[nl..] with the normalised entries while the
+    // other workgroups still need the raw ones; wl_out: the same for the next iteration
+    if (*done) return;
+    __shared__ double hs[kMaxNv], lam[kMaxNv * 8], ys[8], xs[8], ts[8], sc[2 + 8];
+    // ---- scalars, derived by every workgroup ----
+    if (threadIdx.x < kWave) {  // lane i owns basis vector i (nv <= 63)
+        const int i = threadIdx.x;
+        const double hi = i < nv ? dots[i] : 0.0;
+        if (i < nv) hs[i] = hi;
+        const double hh = wave_sum(hi * hi);
+        double tsum[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tsum[r] = r < m ? wave_sum(i < nv ? hi * tb[i * 8 + r] : 0.0) : 0.0;
+        if (i == 0) {
+            double tt2 = dots[nv + m] - hh;
+            if (!(tt2 > 0.0)) tt2 = 0.0;
+            sc[0] = tt2;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < m) sc[2 + r] = dots[nv + r] - tsum[r];  // B D w'
+        }
+    }
+    for (int t = threadIdx.x; t < nv * m; t += T) lam[t] = V[(size_t)(t / m) * ldv + nl + (t % m)];
+    __syncthreads();
+    const double tt2 = sc[0];
+    const double tt = sqrt(tt2);
+    const double inv_tt = tt > 1e-300 ? 1.0 / tt : 1.0;
+    if ((int)threadIdx.x < MP) {
+        const int r = threadIdx.x;
+        double x1 = 0.0, t = 0.0, y = 0.0, wraw = 0.0;
+        if (r < m) {
+            wraw = wl_in[r];
+            for (int i = 0; i < nv; ++i) wraw += -hs[i] * lam[i * m + r];  // the MAXPY of the lambda entries
+            x1 = wraw * inv_tt;
+            t = sc[2 + r] * inv_tt;
+            y = -(x1 - t) / shat[r];
+        }
+        xs[r] = x1;
+        ts[r] = t;
+        ys[r] = y;
+        if (blockIdx.x == 0 && r < m) w1side[r] = wraw;
+    }
+    __syncthreads();
+    double yv[MP];
+#pragma unroll
+    for (int r = 0; r < MP; ++r) yv[r] = ys[r];
+
+    // workgroup 0: the m multiplier entries, the recurrence data of the next iteration, Givens
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < m) {
+            const int r = threadIdx.x;
+            double w1 = ts[r];
+            if (fact == SPK_SCHUR_FULL)
+                for (int q = 0; q < m; ++q) w1 -= gram[r * m + q] * ys[q];
+            w[nl + r] = xs[r];
+            z[nl + r] = ys[r];
+            c[nl + r] = w1;
+            wl_out[r] = w1;
+            nrm_out[1 + r] = sc[2 + r];
+            tb[nv * 8 + r] = tt2 > 0.0 ? sc[2 + r] * (1.0 / tt) : 0.0;
+        }
+        if (threadIdx.x == 0) nrm_out[0] = tt2;
+        __syncthreads();
+        givens_block(ka, loc, dots, nrm_out);
+        return;
+    }
+    const int bid = (int)blockIdx.x - 1;
+    const int64_t n2 = nl / 2;
+    const int gmain = (int)gridDim.x - 1 - (sr.peer ? (2 * sr.nrecv + T - 1) / T : 0);
+    if (bid >= gmain) {  // peer-store halo: unpack this rank's ghost rows (see fused_head_kernel)
+        const int64_t g = (int64_t)(bid - gmain) * T + threadIdx.x;
+        if (g < 2 * (int64_t)sr.nrecv) {
+            uint32_t lo;
+            const bool ok = granule_wait(sr.mine + g, sr.seq, sr.timeout_ms, lo, sr.err, done);
+            const uint32_t other = __shfl_xor(lo, 1, kWave);
+            if (!(g & 1)) sr.xghost[g >> 1] = join_halves(lo, other);
+            if (!ok) __hip_atomic_store(sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const int bx = sr.peer ? ((bid & 1) ? gmain - 1 - (bid >> 1) : (bid >> 1)) : bid;
+    for (int64_t tile = bx; tile * (T * U) < n2; tile += gmain) {
+        double2 wv[U], dv[U], sv[U];
+        int64_t idx[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = tile * (T * U) + u * T + threadIdx.x;
+            ok[u] = idx[u] < n2;
+            if (!ok[u]) idx[u] = 0;
+            wv[u] = ld2(w, idx[u]);
+            dv[u] = ld2(dinv, idx[u]);
+            sv[u].x = sv[u].y = 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < MP; ++r) {
+            if (r < m) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double2 e = ld2s<true>(bd + (size_t)r * ldb, idx[u]);
+                    sv[u].x += e.x * yv[r];
+                    sv[u].y += e.y * yv[r];
+                }
+            }
+        }
+        for (int g0 = 0; g0 < nv; g0 += G) {
+            double2 t[G][U];
+            double ai[G];
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+                const bool live = g0 + v < nv;
+                const int ic = live ? g0 + v : 0;
+                ai[v] = live ? -hs[ic] : 0.0;
+                const double *Vi = V + (size_t)ic * ldv;
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[v][u] = ld2s<true>(Vi, live ? idx[u] : 0);
+            }
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wv[u].x += ai[v] * t[v][u].x;
+                    wv[u].y += ai[v] * t[v][u].y;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+                const int64_t i = idx[u];
+                double2 vn, zz, cc;
+                vn.x = wv[u].x * inv_tt;
+                vn.y = wv[u].y * inv_tt;
+                zz.x = vn.x * dv[u].x;
+                zz.y = vn.y * dv[u].y;
+                if (fact == SPK_SCHUR_FULL) {
+                    zz.x -= sv[u].x;
+                    zz.y -= sv[u].y;
+                }
+                cc.x = sv[u].x / dv[u].x;
+                cc.y = sv[u].y / dv[u].y;
+                reinterpret_cast<double2 *>(w)[i] = vn;
+                reinterpret_cast<double2 *>(z)[i] = zz;
+                reinterpret_cast<double2 *>(c)[i] = cc;
+                for (int q = 0; q < sr.n; ++q) {
+                    const int64_t e = 2 * i - sr.r0[q];
+                    if (sr.peer) {
+                        const unsigned long long tag = (unsigned long long)sr.seq << 32;
+                        if (e >= 0 && e < sr.len[q]) {
+                            const unsigned long long b = (unsigned long long)__double_as_longlong(zz.x);
+                            st_sys(sr.remote[q] + 2 * e, tag | (b & 0xffffffffull));
+                            st_sys(sr.remote[q] + 2 * e + 1, tag | (b >> 32));
+                        }
+                        if (e + 1 >= 0 && e + 1 < sr.len[q]) {
+                            const unsigned long long b = (unsigned long long)__double_as_longlong(zz.y);
+                            st_sys(sr.remote[q] + 2 * e + 2, tag | (b & 0xffffffffull));
+                            st_sys(sr.remote[q] + 2 * e + 3, tag | (b >> 32));
+                        }
+                    } else {
+                        if (e >= 0 && e < sr.len[q]) sr.buf[sr.off[q] + e] = zz.x;
+                        if (e + 1 >= 0 && e + 1 < sr.len[q]) sr.buf[sr.off[q] + e + 1] = zz.y;
+                    }
+                }
+            }
+        }
+    }
+}
+void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double *tb, double *nrm_out, double *w,
+                const double *dinv, const double *bd, int64_t ldb, const double *shat, const double *gram, int fact,
+                int64_t nl, int m, double *z, double *c, double *w1side, const double *wl_in, double *wl_out,
+                const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *srp)
+{
+    const int64_t n2 = nl / 2;
+    SendRanges sr{};
+    if (srp) sr = *srp;
+    // thin workgroups below 0.5 M entries (as MAXPY), fat ones above
+    const bool thin = n2 < (int64_t)kVecMaxBlocks * 2048;
+    const int T = thin ? 256 : 512, U = thin ? (n2 < (int64_t)kVecMaxBlocks * 1024 ? 1 : 2) : 4;
+    int64_t tiles = (n2 + (int64_t)T * U - 1) / ((int64_t)T * U);
+    if (tiles < 1) tiles = 1;
+    int grid = (int)std::min<int64_t>(tiles, thin ? 1024 : kVecMaxBlocks);
+    grid += 1;
+    if (sr.peer) grid += (2 * sr.nrecv + T - 1) / T;
+#define SPK_MH(TT, GG, UU, MPP) hipLaunchKernelGGL((maxpy_head_kernel<TT, GG, UU, MPP>), dim3(grid), dim3(TT), 0, s, V, ldv, nv, dots, tb, \
+                                                   nrm_out, w, dinv, bd, ldb, shat, gram, fact, nl, m, z, c, w1side, wl_in, wl_out, ka, loc, sr, done)
+    if (m <= 4) {
+        if (!thin) SPK_MH(512, 4, 4, 4);
+        else if (U == 2) SPK_MH(256, 8, 2, 4);
+        else SPK_MH(256, 8, 1, 4);
+    } else {
+        if (!thin) SPK_MH(512, 4, 4, 8);
+        else if (U == 2) SPK_MH(256, 8, 2, 8);
+        else SPK_MH(256, 8, 1, 8);
+    }
+#undef SPK_MH
+}
+
 // -ksp_gmres_cgs_refinement_type: mode 2 (always) refines unless done; mode 1 (ifneeded)
 // refines when ||w'|| < ||h|| (PETSc's test); the second-pass kernels take skip_refine as
 // their "done" word.  dots2 is zeroed so that a skipped pass merges as a no-op.

@@ -587,6 +587,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
 
         bool stop = false;
         int last = -1;  // last iteration of this cycle whose Givens step is still pending (fused path)
+        // single-reduction mode: the MAXPY of iteration loc also runs the head of iteration loc+1 and the
+        // Givens step of iteration loc (k::maxpy_head): three launches and one reduction per iteration
+        bool head_done = false, prev_inhead = false;
+        auto wl = [&](int p) { return sm + 400 + (p & 1) * 8; };  // lambda entries of w, side copies
         for (int loc = 0; loc < mk && !stop; ++loc) {
             double *w = Vj(loc + 1);
             double *db = dotsbuf(loc), *nb = nrmbuf(loc);
@@ -595,11 +599,15 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 // workgroup 0 also runs the Givens step of iteration loc-1
                 k::SendRanges sr = c->send_ranges;
                 const bool packed = sr.n > 0;   // head fills the halo buffer itself ...
-                const bool inhead = packed && c->comm->fused_halo(sr, c->xghost.p);   // ... or does the whole exchange
-                k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
-                              c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
-                              packed ? &sr : nullptr);
-                last = loc;
+                bool inhead = prev_inhead;
+                if (!head_done) {
+                    inhead = packed && c->comm->fused_halo(sr, c->xghost.p);   // ... or does the whole exchange
+                    k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
+                                  c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
+                                  packed ? &sr : nullptr);
+                    last = loc;
+                    if (single) k::copy_small(w + nl, wl(loc), m, done, s);
+                }
                 // w += A z0 (halo exchange, then diagonal and off-rank columns in ONE kernel)
                 const k::OffDiag od = c->offdiag();
                 if (!c->peers.empty() && !inhead) {
@@ -633,9 +641,21 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 const k::PeerAR ar = loc + 1 + m <= 40 ? c->comm->fused_allreduce(loc + 2 + m) : k::PeerAR{};
                 k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, c->bd.p, m);
                 if (!ar.P) c->comm->allreduce_sum(db, loc + 2 + m, s);
-                k::PythArgs py{m, db, c->ka.tb, nb};
-                k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nullptr), done, s, nullptr, ld, nl, m,
-                         w1side, &py);
+                if (loc + 1 < mk) {
+                    k::SendRanges sr = c->send_ranges;
+                    prev_inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
+                    k::maxpy_head(V, ld, loc + 1, db, c->ka.tb, nb, w, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
+                                  c->schur_fact, nl, m, Zj(loc + 1), Vj(loc + 2), w1side, wl(loc), wl(loc + 1), c->ka, loc,
+                                  done, s, sr.n > 0 ? &sr : nullptr);
+                    head_done = true;
+                    last = -1;  // its Givens step is done
+                } else {
+                    k::PythArgs py{m, db, c->ka.tb, nb};
+                    k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nullptr), done, s, nullptr, ld, nl, m,
+                             w1side, &py);
+                    head_done = false;
+                    last = loc;
+                }
             } else {
                 // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
                 // across ranks the all-reduces ride in the finish of the two kernels (peer-store backend)

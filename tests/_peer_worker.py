@@ -49,6 +49,7 @@ def main():
 
     # (name, dim, grid, pc, fact, inner sweeps, fused)
     cases = [("schur_full", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
+             ("schur_full_single", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
              ("schur_lower_unfused", 2, (24, 26), S.PC_SCHUR, S.SCHUR_LOWER, 0, 0),
              ("jacobi", 2, (24, 26), S.PC_JACOBI, 0, 0, 1),
              ("schur_diag_fp32", 2, (24, 26), S.PC_SCHUR, S.SCHUR_DIAG, 3, 1),
@@ -80,7 +81,7 @@ def main():
             c.pc_setup(pc, fact, inner_sweeps=inner, inner_omega=0.8)
             y = c.mult(xin)
             z = c.pc_apply(xin)
-            x, info = c.fgmres(rhs, rtol=1e-9, fused=fused)
+            x, info = c.fgmres(rhs, rtol=1e-9, fused=fused, single_reduce=int(name.endswith("_single")))
             k = f"{name}/{peer}/"
             res[k + "y"], res[k + "z"], res[k + "x"] = y, z, x
             res[k + "hist"] = info["history"]

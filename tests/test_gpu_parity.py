@@ -644,7 +644,8 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
     _launch_peer_worker(tmp_path, P, "cases", 29650 + P + (10 if halo_max else 0),
                         {"SPK_PEER_HALO_MAX": halo_max} if halo_max else None)
     R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
-    cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_lower_unfused", 2, (24, 26), oracle.PC_SCHUR, 1, 0),
+    cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_full_single", 2, (24, 26), oracle.PC_SCHUR, 3, 0),
+             ("schur_lower_unfused", 2, (24, 26), oracle.PC_SCHUR, 1, 0),
              ("jacobi", 2, (24, 26), oracle.PC_JACOBI, 0, 0), ("schur_diag_fp32", 2, (24, 26), oracle.PC_SCHUR, 0, 3),
              ("jacobi_3d_fp32", 3, (10, 9, 12), oracle.PC_JACOBI, 0, 3)]
     for name, dim, grid, pc, fact, inner in cases:
