@@ -562,7 +562,7 @@ def test_driver_executable_reference_default_problem(spk, appendix_b, golden_m32
 
 
 # --------------------------------------------------------------------------- partitioned algorithm on one GPU
-def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, inner=0, **kw):
+def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, inner=0, try_peer=False, **kw):
     import threading
     grp = spk.LocalGroup(P)
     out, errs = [None] * P, []
@@ -574,6 +574,8 @@ def _run_ranks(spk, P, mx, my, pc, fact, rhs_full, with_B, inner=0, **kw):
             A, _ = spk.AssembleOperator_Laplace(mx, my, b, e)
             c = spk.Context(0)
             c.comm_init_local(grp, r)
+            if try_peer:   # refused for ranks of one process: the communicator set before must keep working
+                assert not c.comm_enable_peer() and c.comm_backend() == "local"
             c.set_block(spk.BLOCK_A00, A)
             if with_B:
                 Bs, _ = spk.AssembleOperator_Constraints(mx, my, b, e)
@@ -604,7 +606,8 @@ def test_row_partitioned_solver_matches_single_rank(spk, oracle, P, single):
     B, g = spk.AssembleOperator_Constraints(mx, my)
     rhs = np.concatenate([f, g])
     n = A.nrows
-    out = _run_ranks(spk, P, mx, my, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=1e-10, single_reduce=single)
+    out = _run_ranks(spk, P, mx, my, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=1e-10, single_reduce=single,
+                     try_peer=(P == 3))
     y_ref = oracle.apply_K(A, B, rhs)
     z_ref = oracle.pc_apply(A, B, oracle.PC_SCHUR, 3, rhs)
     xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10)
