@@ -232,7 +232,7 @@ def main():
     # per iteration instead of two and four; ||w'||^2 by Pythagoras, see include/spk.h).  Reported
     # beside `value`, never as `value`: PETSc's default Gram-Schmidt makes two reductions.
     single_mode = None
-    if saddle and args.pc in ("schur-full", "schur-lower") and args.inner_sweeps == 0 and args.single_reduce == 0:
+    if args.pc in ("schur-full", "schur-lower", "jacobi") and args.inner_sweeps == 0 and args.single_reduce == 0:
         kws = dict(kw, single_reduce=1)
         ctx.fgmres_device(b_dev, x_dev, max_it=min(args.warmup, 30) or 1, **kws)
         barrier()

@@ -2034,11 +2034,13 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
                     zz.x -= sv[u].x;
                     zz.y -= sv[u].y;
                 }
-                cc.x = sv[u].x / dv[u].x;
-                cc.y = sv[u].y / dv[u].y;
                 reinterpret_cast<double2 *>(w)[i] = vn;
                 reinterpret_cast<double2 *>(z)[i] = zz;
-                reinterpret_cast<double2 *>(c)[i] = cc;
+                if (c) {  // nullptr: Jacobi head (K = A, m = 0), the next product is not pre-loaded
+                    cc.x = sv[u].x / dv[u].x;
+                    cc.y = sv[u].y / dv[u].y;
+                    reinterpret_cast<double2 *>(c)[i] = cc;
+                }
                 for (int q = 0; q < sr.n; ++q) {
                     const int64_t e = 2 * i - sr.r0[q];
                     if (sr.peer) {

@@ -572,7 +572,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // come out of ONE pass and ONE all-reduce; ||w'||^2 = w.w - |h|^2 and B D w' = q - sum h_i B D v_i
     // follow without touching w' -- one collective per iteration instead of two.
     // Opt-in (opts.single_reduce = 1): the subtraction cancels, see include/spk.h.
-    const bool single = fused && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
+    // The Jacobi head path (K = A) takes the same route with m = 0: ||w'||^2 = w.w - |h|^2 only.
+    const bool single = head && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                         o.single_reduce == 1;
 
     KrylovState st{};
@@ -617,11 +618,14 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
                 else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
             } else if (fusedj) {
-                k::SendRanges sr = c->send_ranges;
-                const bool inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
-                k::fused_head(Vj(loc), nrmbuf(loc + 1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER,
-                              nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s, inhead ? &sr : nullptr);
-                last = loc;
+                bool inhead = prev_inhead;
+                if (!head_done) {
+                    k::SendRanges sr = c->send_ranges;
+                    inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
+                    k::fused_head(Vj(loc), nrmbuf(loc + 1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER,
+                                  nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s, inhead ? &sr : nullptr);
+                    last = loc;
+                }
                 op_mult(c, Zj(loc), w, done, inhead);    // w = A z_j (halo inside, unless the head kernel did it)
             } else {
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
@@ -644,9 +648,11 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 if (loc + 1 < mk) {
                     k::SendRanges sr = c->send_ranges;
                     prev_inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
-                    k::maxpy_head(V, ld, loc + 1, db, c->ka.tb, nb, w, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
-                                  c->schur_fact, nl, m, Zj(loc + 1), Vj(loc + 2), w1side, wl(loc), wl(loc + 1), c->ka, loc,
-                                  done, s, sr.n > 0 ? &sr : nullptr);
+                    // Schur: the packed halo buffer is filled even without the peer backend; Jacobi: op_mult gathers
+                    const k::SendRanges *srp = sr.n > 0 && (fused || prev_inhead) ? &sr : nullptr;
+                    k::maxpy_head(V, ld, loc + 1, db, c->ka.tb, nb, w, c->dinv.p, bdp, ld, c->shat.p, c->gram.p,
+                                  fused ? c->schur_fact : SPK_SCHUR_LOWER, nl, m, Zj(loc + 1), fused ? Vj(loc + 2) : nullptr,
+                                  w1side, wl(loc), wl(loc + 1), c->ka, loc, done, s, srp);
                     head_done = true;
                     last = -1;  // its Givens step is done
                 } else {

@@ -52,6 +52,7 @@ def main():
              ("schur_full_single", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
              ("schur_lower_unfused", 2, (24, 26), S.PC_SCHUR, S.SCHUR_LOWER, 0, 0),
              ("jacobi", 2, (24, 26), S.PC_JACOBI, 0, 0, 1),
+             ("jacobi_single", 2, (24, 26), S.PC_JACOBI, 0, 0, 1),
              ("schur_diag_fp32", 2, (24, 26), S.PC_SCHUR, S.SCHUR_DIAG, 3, 1),
              ("jacobi_3d_fp32", 3, (10, 9, 12), S.PC_JACOBI, 0, 3, 1)]
     for name, dim, grid, pc, fact, inner, fused in cases:

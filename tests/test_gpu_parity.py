@@ -239,6 +239,24 @@ def test_single_reduction_gram_schmidt(spk, oracle, fact):
     assert relerr(x1, x2) < 1e-8 and relerr(x1, xo) < 1e-8
 
 
+def test_single_reduction_jacobi_head_path(spk, oracle):
+    """The same single-reduction route on the Jacobi head path (K = A, the reference as written):
+    ||w'||^2 = w.w - |h|^2, MAXPY + VecScale + PCApply_Jacobi + Givens in one launch."""
+    A, f = spk.AssembleOperator_Laplace(40, 28)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.pc_setup(spk.PC_JACOBI)
+        x1, i1 = c.fgmres(f, rtol=1e-10, single_reduce=1)
+        x2, i2 = c.fgmres(f, rtol=1e-10, single_reduce=0)
+        x3, i3 = c.fgmres(f, rtol=1e-10, single_reduce=1, restart=1)     # degenerate cycle: no fused launch at all
+    xo, io = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, rtol=1e-10)
+    assert i1["reason"] == i2["reason"] == 2
+    assert abs(i1["its"] - i2["its"]) <= 1 and abs(i1["its"] - io["its"]) <= 1
+    assert np.allclose(i1["history"][:21], i2["history"][:21], rtol=1e-5)
+    assert relerr(x1, x2) < 1e-8 and relerr(x1, xo) < 1e-8
+    assert i3["reason"] in (2, -3)
+
+
 @pytest.mark.parametrize("pc,fact", [("jacobi", 0), ("schur", 0), ("schur", 1), ("schur", 2), ("schur", 3)])
 def test_fp32_inner_solve(spk, oracle, pc, fact):
     """BASELINE config 5's "mixed FP32 inner solve": k damped-Jacobi Richardson sweeps on A in single
@@ -649,7 +667,8 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
     R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
     cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_full_single", 2, (24, 26), oracle.PC_SCHUR, 3, 0),
              ("schur_lower_unfused", 2, (24, 26), oracle.PC_SCHUR, 1, 0),
-             ("jacobi", 2, (24, 26), oracle.PC_JACOBI, 0, 0), ("schur_diag_fp32", 2, (24, 26), oracle.PC_SCHUR, 0, 3),
+             ("jacobi", 2, (24, 26), oracle.PC_JACOBI, 0, 0), ("jacobi_single", 2, (24, 26), oracle.PC_JACOBI, 0, 0),
+             ("schur_diag_fp32", 2, (24, 26), oracle.PC_SCHUR, 0, 3),
              ("jacobi_3d_fp32", 3, (10, 9, 12), oracle.PC_JACOBI, 0, 3)]
     for name, dim, grid, pc, fact, inner in cases:
         saddle = pc == oracle.PC_SCHUR
