@@ -88,17 +88,22 @@ typedef struct spk_opts {
     int32_t fused;          /* 1: fused PC+operator kernels where the PC allows,
                                0: PCApply and MatMult as separate steps */
     int32_t cgs_refine;     /* -ksp_gmres_cgs_refinement_type: SPK_REFINE_* (never) */
-    int32_t single_reduce;  /* fused CGS only, OFF by default: 1 = h = V^T w, B D w and w.w from ONE
-                               pass and ONE all-reduce per iteration; ||w'||^2 = w.w - |h|^2 and
-                               B D w' by recurrence.  Every scalar the next iteration's head needs
+    int32_t single_reduce;  /* head-kernel paths with CGS only, OFF by default: 1 = h = V^T w, B D w and
+                               w.w from ONE pass and ONE all-reduce per iteration; ||w'||^2 = w.w - |h|^2
+                               and B D w' by recurrence.  Every scalar the next iteration's head needs
                                is then known before the update starts, so MAXPY, VecScale, PCApply
                                and the Givens step run as ONE launch: three launches per iteration
-                               instead of four (1024^2: 227 -> 219 us, a 1/8 slab: 51 -> 45 us).
-                               Saves a collective per iteration on many
-                               GPUs but the subtraction cancels (||w'|| << ||w|| behind a good
-                               preconditioner): measured 5e-6 relative drift of the residual
-                               history inside the first cycle at 1024^2 (two-reduction path:
-                               3e-11), converged solutions still agree to the tolerance. */
+                               instead of four (1024^2: 227 -> 219 us, a 1/8 slab: 51 -> 45 us) and one
+                               collective per iteration instead of two on many GPUs.  The price: the
+                               subtraction cancels (||w'|| << ||w|| behind a good preconditioner):
+                               measured 5e-6 relative drift of the residual history inside the
+                               first cycle at 1024^2 (two-reduction path: 3e-11).  Safeguards: below
+                               64 eps w.w the difference is kept at that floor (an over-estimated
+                               ||w'|| over-estimates the residual), and a convergence seen by the
+                               recurrence only ENDS THE CYCLE -- the solve ends when the true
+                               residual computed at the restart confirms it, never on the
+                               recurrence alone.  Needs restart + m <= 63 (falls back to two
+                               reductions otherwise). */
     int32_t reserved[2];
 } spk_opts;
 

@@ -223,6 +223,10 @@ void split_csr(int64_t row_begin, int32_t nrows_local, const int32_t *rowptr,
 struct KrylovState {
     int32_t its, reason, done, loc_done;
     int32_t max_it, restart, hapend, skip_refine;
+    // what the kernels of an ITERATION are gated by: set together with `done`, and alone when the
+    // rest of the restart cycle is to be skipped (single-reduction mode: a convergence seen by the
+    // recurrence is only tentative and is confirmed on the true residual of the restart)
+    int32_t skip_iter, pad_;
     double rnorm, rnorm0, ttol, abstol, dtol, bnorm;
     double inv_tt;  // 1/||w|| of the last orthogonalised vector (or 1/||r||)
     double tt;
@@ -346,6 +350,7 @@ struct KrylovArrays {
     KrylovState *st;
     double *H, *cc, *ss, *rs, *nrs, *hcol, *hist, *tb;
     int32_t hist_cap, ldh;
+    int32_t tentative;  // 1: the recurrence may end a cycle, only a true residual may end the solve
 };
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
 void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0);

@@ -910,8 +910,13 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
 #pragma unroll
         for (int r = 0; r < 8; ++r) tsum[r] = r < py.m ? wave_sum(i < nv ? hi * py.tb[i * 8 + r] : 0.0) : 0.0;
         if (i == 0) {
-            double tt2 = py.dots[nv + py.m] - hh;
-            if (!(tt2 > 0.0)) tt2 = 0.0;
+            // below ~64 eps w.w the difference is rounding noise (it can even come out negative): keep
+            // the floor instead -- an over-estimated ||w'|| over-estimates the residual norm, so the
+            // recurrence can never report a convergence that the true residual of the next restart
+            // would not confirm (a zero here would read as a happy breakdown)
+            const double ww = py.dots[nv + py.m];
+            double tt2 = ww - hh;
+            if (!(tt2 > 1.5e-14 * ww)) tt2 = 1.5e-14 * ww;
             py.nrm_out[0] = tt2;
             const double inv = tt2 > 0.0 ? 1.0 / sqrt(tt2) : 0.0;
 #pragma unroll
@@ -1590,6 +1595,7 @@ __global__ void krylov_init_kernel(KrylovArrays ka, spk_opts o, const double *bn
     st->restart = o.restart;
     st->hapend = 0;
     st->skip_refine = 1;
+    st->skip_iter = 0;
     st->bnorm = sqrt(*bnorm2);
     st->abstol = o.abstol;
     st->dtol = o.dtol;
@@ -1609,6 +1615,7 @@ __global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, d
     if (threadIdx.x != 0) return;
     KrylovState *st = ka.st;
     st->loc_done = 0;
+    st->skip_iter = st->done;  // a cycle ended early by the recurrence starts afresh here
     if (st->done) return;
     const double rnorm = sqrt(*nrm2);
     st->rnorm = rnorm;
@@ -1622,6 +1629,7 @@ __global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, d
     st->hapend = 0;
     if (reason) {
         st->done = 1;
+        st->skip_iter = 1;
         return;
     }
     ka.rs[0] = rnorm;
@@ -1643,7 +1651,7 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
 {
     __shared__ double Hc[kMaxNv + 2], Hr[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
     KrylovState *st = ka.st;
-    if (st->done) return;  // uniform: read before anyone writes it
+    if (st->done || st->skip_iter) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
     double *Hg = ka.H + (size_t)ldh * loc;  // column loc
     // every global value the serial chain needs is fetched here, in parallel, once
@@ -1662,6 +1670,7 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
         st->rnorm = tt;
         st->reason = SPK_DIVERGED_NANORINF;
         st->done = 1;
+        st->skip_iter = 1;
         return;
     }
     // happy breakdown test
@@ -1690,6 +1699,7 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
         if (d == 0.0) {
             st->reason = SPK_DIVERGED_NULL;
             st->done = 1;
+            st->skip_iter = 1;
             return;
         }
         const double c = h0 / d, sn = h1 / d;
@@ -1711,8 +1721,17 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
     reason = converged_default(rnorm, st);
     if (hapend && !reason) reason = SPK_DIVERGED_BREAKDOWN;
     if (!reason && st->its >= st->max_it) reason = SPK_DIVERGED_ITS;
+    if (reason > 0 && ka.tentative) {
+        // single-reduction mode: ||w'|| came out of a difference that can sit in rounding noise, so the
+        // recurrence is trusted to END THE CYCLE only; the restart's true residual decides (krylov_cycle_begin)
+        st->skip_iter = 1;
+        return;
+    }
     st->reason = reason;
-    if (reason) st->done = 1;
+    if (reason) {
+        st->done = 1;
+        st->skip_iter = 1;
+    }
 }
 
 __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
@@ -1909,8 +1928,9 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
 #pragma unroll
         for (int r = 0; r < 8; ++r) tsum[r] = r < m ? wave_sum(i < nv ? hi * tb[i * 8 + r] : 0.0) : 0.0;
         if (i == 0) {
-            double tt2 = dots[nv + m] - hh;
-            if (!(tt2 > 0.0)) tt2 = 0.0;
+            const double ww = dots[nv + m];
+            double tt2 = ww - hh;
+            if (!(tt2 > 1.5e-14 * ww)) tt2 = 1.5e-14 * ww;  // noise floor of the difference, see maxpy_kernel
             sc[0] = tt2;
 #pragma unroll
             for (int r = 0; r < 8; ++r)

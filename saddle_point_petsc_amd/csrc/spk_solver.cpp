@@ -573,9 +573,11 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // follow without touching w' -- one collective per iteration instead of two.
     // Opt-in (opts.single_reduce = 1): the subtraction cancels, see include/spk.h.
     // The Jacobi head path (K = A) takes the same route with m = 0: ||w'||^2 = w.w - |h|^2 only.
+    // (MDot then carries restart + m vectors: both must fit one reduction.)
     const bool single = head && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
-                        o.single_reduce == 1;
+                        o.single_reduce == 1 && mk + c->m <= k::kMaxNv - 1;
 
+    c->ka.tentative = single ? 1 : 0;
     KrylovState st{};
     int cycles = 0;
     for (;;) {
@@ -593,6 +595,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         bool head_done = false, prev_inhead = false;
         auto wl = [&](int p) { return sm + 400 + (p & 1) * 8; };  // lambda entries of w, side copies
         for (int loc = 0; loc < mk && !stop; ++loc) {
+            const int32_t *done = &c->kst.p->skip_iter;  // the gate of everything inside an iteration
             double *w = Vj(loc + 1);
             double *db = dotsbuf(loc), *nb = nrmbuf(loc);
             if (fused) {
@@ -692,7 +695,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             if (o.check_every > 0 && (loc + 1) % o.check_every == 0 && loc + 1 < mk) {
                 SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
                 SPK_HIP(hipStreamSynchronize(s));
-                stop = st.done != 0;  // fused path: lags by one iteration, the iterate does not care
+                stop = st.done != 0 || st.skip_iter != 0;  // fused path: lags by one iteration, the iterate does not care
             }
         }
         // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
