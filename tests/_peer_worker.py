@@ -47,9 +47,15 @@ def main():
         dist.destroy_process_group()
         return
 
-    # (name, dim, grid, pc, fact, inner sweeps, fused)
+    # (name, dim, grid, pc, fact, inner sweeps, fused); solver options by name suffix, see OPTS
+    OPTS = {"single": dict(single_reduce=1), "mgs": dict(orthog=1), "refine": dict(cgs_refine=1),
+            "r62": dict(restart=62), "guess": dict()}
     cases = [("schur_full", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
              ("schur_full_single", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
+             ("schur_full_mgs", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
+             ("schur_full_refine", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
+             ("schur_full_r62", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
+             ("schur_full_guess", 2, (24, 26), S.PC_SCHUR, S.SCHUR_FULL, 0, 1),
              ("schur_lower_unfused", 2, (24, 26), S.PC_SCHUR, S.SCHUR_LOWER, 0, 0),
              ("jacobi", 2, (24, 26), S.PC_JACOBI, 0, 0, 1),
              ("jacobi_single", 2, (24, 26), S.PC_JACOBI, 0, 0, 1),
@@ -82,7 +88,9 @@ def main():
             c.pc_setup(pc, fact, inner_sweeps=inner, inner_omega=0.8)
             y = c.mult(xin)
             z = c.pc_apply(xin)
-            x, info = c.fgmres(rhs, rtol=1e-9, fused=fused, single_reduce=int(name.endswith("_single")))
+            okw = OPTS.get(name.rsplit("_", 1)[-1], {})
+            x0 = 0.01 * xin if name.endswith("_guess") else None          # -ksp_initial_guess_nonzero
+            x, info = c.fgmres(rhs, x0=x0, rtol=1e-9, fused=fused, **okw)
             k = f"{name}/{peer}/"
             res[k + "y"], res[k + "z"], res[k + "x"] = y, z, x
             res[k + "hist"] = info["history"]

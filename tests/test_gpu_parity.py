@@ -692,7 +692,10 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
     _launch_peer_worker(tmp_path, P, "cases", 29650 + P + (10 if halo_max else 0),
                         {"SPK_PEER_HALO_MAX": halo_max} if halo_max else None)
     R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
+    okws = {"mgs": dict(orthog=1), "refine": dict(refine=1), "r62": dict(restart=62)}
     cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_full_single", 2, (24, 26), oracle.PC_SCHUR, 3, 0),
+             ("schur_full_mgs", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_full_refine", 2, (24, 26), oracle.PC_SCHUR, 3, 0),
+             ("schur_full_r62", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_full_guess", 2, (24, 26), oracle.PC_SCHUR, 3, 0),
              ("schur_lower_unfused", 2, (24, 26), oracle.PC_SCHUR, 1, 0),
              ("jacobi", 2, (24, 26), oracle.PC_JACOBI, 0, 0), ("jacobi_single", 2, (24, 26), oracle.PC_JACOBI, 0, 0),
              ("schur_diag_fp32", 2, (24, 26), oracle.PC_SCHUR, 0, 3),
@@ -711,6 +714,9 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
         rhs = np.concatenate([f, g])
         xin = np.concatenate([np.sin(0.37 * np.arange(n)), 0.5 + np.arange(m)])
         kw = dict(inner_its=inner, inner_omega=0.8) if inner else {}
+        kw.update(okws.get(name.rsplit("_", 1)[-1], {}))
+        if name.endswith("_guess"):
+            kw["x0"] = 0.01 * xin
         xo, io = oracle.fgmres(Ao, rhs, B=Bo, pc_type=pc, schur_fact=fact, rtol=1e-9, **kw)
         y_ref = oracle.apply_K(Ao, Bo, xin) if saddle else oracle.spmv(Ao, xin)
         got = {}
