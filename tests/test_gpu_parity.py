@@ -516,6 +516,50 @@ def test_spmv_random_csr(spk, oracle, seed):
         assert np.array_equal(c.mult(x), oracle.spmv(A, x))
 
 
+@pytest.mark.parametrize("n,m", [(1001, 0), (1001, 3), (777, 5), (4098, 4)])
+def test_fgmres_general_matrix_odd_sizes(spk, oracle, n, m):
+    """A general (non-grid) operator: random diagonally dominant CSR with ragged rows, an ODD number of
+    rows (no 2x2 blocks, no fused head path: PCApply and MatMult as separate steps) and a random
+    constraint block with m rows -- the solver is matrix-agnostic behind KSPSetOperators."""
+    rng = np.random.default_rng(n + m)
+    lens = rng.integers(1, 9, n)
+    rowptr = np.concatenate([[0], np.cumsum(lens + 1)]).astype(np.int32)
+    colidx = np.empty(rowptr[-1], np.int32)
+    val = np.empty(rowptr[-1])
+    for i in range(n):
+        k0, k1 = rowptr[i], rowptr[i + 1]
+        cols = np.sort(rng.choice(n, k1 - k0 - 1, replace=False))
+        cols = np.sort(np.unique(np.concatenate([cols[cols != i], [i]])))
+        cols = np.pad(cols, (0, k1 - k0 - len(cols)), mode="edge")            # duplicates allowed
+        colidx[k0:k1] = cols
+        v = rng.standard_normal(k1 - k0) * 0.3
+        v[cols == i] = 0.0
+        v[np.argmax(cols == i)] = 4.0 + np.abs(v).sum()
+        val[k0:k1] = v
+    A = spk.CSR(rowptr, colidx, val, n)
+    B = None
+    if m:
+        Bd = np.where(rng.random((m, n)) < 0.4, rng.standard_normal((m, n)), 0.0)
+        brp = np.concatenate([[0], np.cumsum((Bd != 0).sum(1))]).astype(np.int32)
+        B = spk.CSR(brp, np.concatenate([np.nonzero(r)[0] for r in Bd]).astype(np.int32), Bd[Bd != 0], n)
+    rhs = rng.standard_normal(n + m)
+    Ao = oracle.CSR(A.rowptr, A.colidx, A.val, n)
+    Bo = oracle.CSR(B.rowptr, B.colidx, B.val, n) if m else None
+    pc, fact = (spk.PC_SCHUR, 3) if m else (spk.PC_JACOBI, 0)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        assert c.spmv_info()["format"] == "csr"
+        if m:
+            c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(pc, fact)
+        x, info = c.fgmres(rhs, rtol=1e-10, max_it=3000)
+    xo, io = oracle.fgmres(Ao, rhs, B=Bo, pc_type=pc, schur_fact=fact, rtol=1e-10, max_it=3000)
+    assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 2
+    assert relerr(x, xo) < 1e-8
+    Kx = oracle.apply_K(Ao, Bo, x) if m else oracle.spmv(Ao, x)
+    assert np.linalg.norm(rhs - Kx) <= 2e-10 * np.linalg.norm(rhs)
+
+
 def test_device_resident_vectors(spk, oracle):
     """b and x already in HBM (SPK_MEM_DEVICE): same iterate as the host-pointer path."""
     A, f = spk.AssembleOperator_Laplace(32)
