@@ -371,6 +371,11 @@ static PetscErrorCode KSPSolve_SPK(KSP ksp)
     o.max_it = ksp->max_it;      /* -ksp_max_it */
     o.guess_nonzero = ksp->guess_zero ? 0 : 1;
     ierr = PetscOptionsGetInt(((PetscObject)ksp)->options, ((PetscObject)ksp)->prefix, "-ksp_gmres_restart", &o.restart, NULL); CHKERRQ(ierr);
+    {   /* private option: one reduction and three launches per iteration (see spk_opts.single_reduce) */
+        PetscInt sr = 0;
+        ierr = PetscOptionsGetInt(((PetscObject)ksp)->options, ((PetscObject)ksp)->prefix, "-spk_single_reduce", &sr, NULL); CHKERRQ(ierr);
+        o.single_reduce = (int32_t)sr;
+    }
     ierr = SpkGather(d->glue, ksp->vec_rhs, d->glue->xbuf); CHKERRQ(ierr);
     if (o.guess_nonzero) { ierr = SpkGather(d->glue, ksp->vec_sol, d->glue->ybuf); CHKERRQ(ierr); }
     SPK_CHK(d->glue->ctx, spk_fgmres(d->glue->ctx, d->glue->xbuf, d->glue->ybuf, SPK_MEM_HOST, &o, &res, NULL, 0));
