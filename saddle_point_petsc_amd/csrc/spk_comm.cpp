@@ -365,46 +365,62 @@ public:
     int size() const override { return P_; }
 
     // maps the all-reduce windows and runs the self-test; false (with *why) when any rank failed
+    // maps the all-reduce windows and runs the self-test; false (with *why) when any rank failed.
+    // Three kinds of window memory are tried in turn -- uncached, fine-grained, plain -- and a kind only
+    // counts when EVERY rank mapped every window and the self-test returned the right sums everywhere
+    // (a kind whose polls cannot see a peer's stores fails it by time-out).
     bool enable(std::string *why)
     {
         const size_t bytes = sizeof(unsigned long long) * (size_t)k::kArSlots * P_ * k::kArGranules;
         std::string mywhy;
-        bool ok = alloc_window(&ar_own_, bytes, &mywhy);
-        ok = share_window(ar_own_, ok, 0, nullptr, ar_map_, nullptr, &mywhy) && ok;
-        ok = agree(ok);
-        if (ok) {
-            // self-test: two all-reduces (two slots) of values that differ per rank and per position
-            // on a stream of its own: logical ranks of one process would queue behind each other on the
-            // null stream, and a rank's kernel waits for the other ranks' kernels
-            DevBuf<double> buf;
-            buf.alloc(64);
-            hipStream_t ts = nullptr;
-            SPK_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
-            for (int round = 0; round < 2 && ok; ++round) {
-                std::vector<double> h(64), r(64);
-                for (int i = 0; i < 64; ++i) h[(size_t)i] = (double)(me_ + 1) * (i + 1 + round) + 0.25 * round;
-                SPK_HIP(hipMemcpy(buf.p, h.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
-                k::PeerAR a = next_ar();
-                a.timeout_ms = 5000;
-                k::peer_allreduce(a, buf.p, 64, ts);
-                SPK_HIP(hipStreamSynchronize(ts));
-                SPK_HIP(hipMemcpy(r.data(), buf.p, 64 * sizeof(double), hipMemcpyDeviceToHost));
-                for (int i = 0; i < 64 && ok; ++i) {
-                    const double want = 0.5 * P_ * (P_ + 1) * (i + 1 + round) + 0.25 * round * P_;
-                    if (r[(size_t)i] != want) {
-                        ok = false;
-                        mywhy = "self-test all-reduce returned a wrong sum";
-                    }
-                }
-                if (error_word()) {
+        bool ok = false;
+        for (tier_ = 0; tier_ < 3 && !ok; ++tier_) {
+            ok = alloc_window(&ar_own_, bytes, &mywhy);
+            ok = share_window(ar_own_, ok, 0, nullptr, ar_map_, nullptr, &mywhy) && ok;
+            ok = agree(ok);
+            if (ok) ok = agree(self_test(&mywhy));
+            if (!ok) {
+                close_maps(ar_map_, ar_own_);
+                if (ar_own_) (void)hipFree(ar_own_);
+                ar_own_ = nullptr;
+                SPK_HIP(hipMemset(err_.p, 0, sizeof(int32_t)));
+            }
+        }
+        --tier_;  // the kind that worked (also used for the halo staging)
+        if (!ok && why) *why = mywhy.empty() ? "another rank could not map the windows" : mywhy;
+        return ok;
+    }
+    // six all-reduces (every slot, and the wrap) of values that differ per rank and per position, on a
+    // stream of its own
+    bool self_test(std::string *why)
+    {
+        bool ok = true;
+        DevBuf<double> buf;
+        buf.alloc(64);
+        hipStream_t ts = nullptr;
+        SPK_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+        for (int round = 0; round < 6 && ok; ++round) {
+            std::vector<double> h(64), r(64);
+            for (int i = 0; i < 64; ++i) h[(size_t)i] = (double)(me_ + 1) * (i + 1 + round) + 0.25 * round;
+            SPK_HIP(hipMemcpy(buf.p, h.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+            k::PeerAR a = next_ar();
+            a.timeout_ms = 5000;
+            k::peer_allreduce(a, buf.p, 64, ts);
+            SPK_HIP(hipStreamSynchronize(ts));
+            SPK_HIP(hipMemcpy(r.data(), buf.p, 64 * sizeof(double), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 64 && ok; ++i) {
+                const double want = 0.5 * P_ * (P_ + 1) * (i + 1 + round) + 0.25 * round * P_;
+                if (r[(size_t)i] != want) {
                     ok = false;
-                    mywhy = "self-test all-reduce timed out";
+                    *why = "self-test all-reduce returned a wrong sum";
                 }
             }
-            (void)hipStreamDestroy(ts);
-            ok = agree(ok);
+            if (error_word()) {
+                ok = false;
+                *why = "self-test all-reduce timed out";
+            }
         }
-        if (!ok && why) *why = mywhy.empty() ? "another rank could not map the windows" : mywhy;
+        (void)hipStreamDestroy(ts);
         return ok;
     }
 
@@ -574,18 +590,19 @@ private:
         for (int32_t v : all) ok = ok && v != 0;
         return ok;
     }
-    static bool alloc_window(unsigned long long **p, size_t bytes, std::string *why)
+    bool alloc_window(unsigned long long **p, size_t bytes, std::string *why)
     {
         *p = nullptr;
-        // uncached (MTYPE UC): a peer's stores must be seen by my polls without any cache maintenance
-        if (hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        // uncached (MTYPE UC) first: a peer's stores must be seen by my polls without any cache
+        // maintenance (what RCCL allocates for its own flags); then fine-grained, then plain
+        hipError_t e = tier_ == 0   ? hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocUncached)
+                       : tier_ == 1 ? hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocFinegrained)
+                                    : hipMalloc((void **)p, bytes);
+        if (e != hipSuccess) {
             (void)hipGetLastError();
-            if (hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-                (void)hipGetLastError();
-                *p = nullptr;
-                *why = "no uncached / fine-grained device memory for the window";
-                return false;
-            }
+            *p = nullptr;
+            *why = "window memory of this kind could not be allocated";
+            return false;
         }
         if (hipMemset(*p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
             (void)hipGetLastError();
@@ -670,6 +687,7 @@ private:
     int device_, P_, me_;
     uint32_t timeout_ms_ = 30000, ar_seq_ = 0, halo_seq_ = 0;
     int halo_max_ = 8192;
+    int tier_ = 0;  // kind of window memory: 0 uncached, 1 fine-grained, 2 plain
     bool fuse_ = true, halo_ok_ = false;
     DevBuf<int32_t> err_;
     unsigned long long *ar_own_ = nullptr, *halo_own_ = nullptr;
