@@ -332,6 +332,7 @@ struct WinInfo {
     hipIpcMemHandle_t handle;
     int32_t ok, device;
     int64_t n_ghost;
+    int64_t max_seg;                    // my longest halo segment (doubles)
     int64_t recv_off_for[k::kPeerMax];  // where rank p's rows land in my ghost array (-1: not a peer)
 };
 
@@ -343,9 +344,10 @@ public:
         timeout_ms_ = t ? (uint32_t)std::max(1, atoi(t)) : 30000u;
         const char *fz = getenv("SPK_PEER_FUSE");  // 0: all-reduces as launches of their own (A/B runs)
         fuse_ = !(fz && !strcmp(fz, "0"));
-        // Granules are the latency tool: 8-byte stores, twice the bytes.  A halo segment beyond this
-        // many doubles (a node PLANE of a 3-D slab: 1.57 MB at 256^3 against 16 KiB for a node line
-        // at 1024^2) is bandwidth-bound and goes through the inner backend's bulk send/recv instead.
+        // Granules are the latency tool: 8-byte tagged stores, twice the bytes.  When any rank has a halo
+        // segment beyond this many doubles (a node PLANE of a 3-D slab: 1.57 MB at 256^3 against 16 KiB
+        // for a node line at 1024^2) the exchange is bandwidth-bound and takes the bulk form: plain
+        // doubles in chunks, one flag per chunk (k::PeerBulk).
         const char *hm = getenv("SPK_PEER_HALO_MAX");
         halo_max_ = hm ? std::max(0, atoi(hm)) : 8192;
         err_.alloc(4);
@@ -449,17 +451,20 @@ public:
         n_ghost_ = n_ghost;
         std::string why;
         bool ok = peers.size() <= 4;
+        int64_t max_seg = 0;
         for (size_t i = 0; i < peers.size(); ++i)
-            ok = ok && send_off[i + 1] - send_off[i] <= halo_max_ && recv_off[i + 1] - recv_off[i] <= halo_max_;
-        // staging: two parities x n_ghost doubles x two granules
-        const size_t bytes = sizeof(unsigned long long) * 4 * (size_t)std::max<int32_t>(ok ? n_ghost : 1, 1);
+            max_seg = std::max(max_seg, std::max(send_off[i + 1] - send_off[i], recv_off[i + 1] - recv_off[i]));
+        // staging: two parities x n_ghost doubles x two granules (the bulk form needs less: data + flags)
+        const size_t bytes = sizeof(unsigned long long) * 4 * (size_t)std::max<int32_t>(n_ghost, 8);
         ok = alloc_window(&halo_own_, bytes, &why) && ok;
         int64_t roff[k::kPeerMax];
         for (int p = 0; p < k::kPeerMax; ++p) roff[p] = -1;
         for (size_t i = 0; i < peers.size(); ++i)
             if (peers[i] < k::kPeerMax) roff[peers[i]] = recv_off[i];
         std::vector<WinInfo> all;
-        ok = share_window(halo_own_, ok, n_ghost, roff, halo_map_, &all, &why) && ok;
+        ok = share_window(halo_own_, ok, n_ghost, roff, halo_map_, &all, &why, max_seg) && ok;
+        bulk_ = false;
+        for (const WinInfo &w : all) bulk_ = bulk_ || w.max_seg > halo_max_;  // the same decision on every rank
         if (ok) {
             halo_peers_ = peers;
             halo_send_off_ = send_off;
@@ -518,6 +523,31 @@ public:
             inner_->exchange(sendbuf, peers, send_off, recvbuf, recv_off, s);
             return;
         }
+        if (bulk_) {
+            k::PeerBulk h{};
+            h.npeers = (int)peers.size();
+            h.seq = ++halo_seq_;
+            h.timeout_ms = timeout_ms_;
+            const size_t par = h.seq & 1u;
+            for (size_t i = 0; i < peers.size(); ++i) {
+                // staging of a rank, in 8-byte units: parity p at p * 2 ng: ng doubles, then ng flag slots
+                unsigned long long *base = halo_map_[peers[i]] + par * 2 * (size_t)halo_remote_ng_[i];
+                h.rdata[i] = reinterpret_cast<double *>(base) + halo_remote_off_[i];
+                h.rflag[i] = base + (size_t)halo_remote_ng_[i] + (size_t)halo_remote_off_[i];
+                h.send_off[i] = send_off[i];
+                h.recv_off[i] = recv_off[i];
+                h.send_chunk0[i + 1] = h.send_chunk0[i] + (int32_t)((send_off[i + 1] - send_off[i] + k::kBulkChunk - 1) / k::kBulkChunk);
+                h.recv_chunk0[i + 1] = h.recv_chunk0[i] + (int32_t)((recv_off[i + 1] - recv_off[i] + k::kBulkChunk - 1) / k::kBulkChunk);
+            }
+            h.send_off[peers.size()] = send_off.back();
+            h.recv_off[peers.size()] = recv_off.back();
+            const unsigned long long *mine = halo_own_ + par * 2 * (size_t)n_ghost_;
+            h.mdata = reinterpret_cast<const double *>(mine);
+            h.mflag = mine + (size_t)n_ghost_;
+            h.err = err_.p;
+            k::peer_exchange_bulk(h, sendbuf, recvbuf, s);
+            return;
+        }
         k::PeerHalo h{};
         h.npeers = (int)peers.size();
         h.seq = ++halo_seq_;
@@ -536,7 +566,7 @@ public:
     }
     bool fused_halo(k::SendRanges &sr, double *xghost) override
     {
-        if (!fuse_ || !halo_ok_ || sr.n != (int)halo_peers_.size() || sr.n < 1) return false;
+        if (!fuse_ || !halo_ok_ || bulk_ || sr.n != (int)halo_peers_.size() || sr.n < 1) return false;
         for (int i = 0; i < sr.n; ++i)
             if (sr.len[i] != halo_send_off_[(size_t)i + 1] - halo_send_off_[(size_t)i]) return false;
         sr.peer = 1;
@@ -613,9 +643,10 @@ private:
     }
     // publishes my window, maps everybody else's; collective (one host all-gather)
     bool share_window(unsigned long long *own, bool ok, int64_t n_ghost, const int64_t *roff, unsigned long long **map,
-                      std::vector<WinInfo> *all_out, std::string *why)
+                      std::vector<WinInfo> *all_out, std::string *why, int64_t max_seg = 0)
     {
         WinInfo mine{};
+        mine.max_seg = max_seg;
         mine.pid = (int64_t)getpid();
         mine.ptr = (uint64_t)(uintptr_t)own;
         mine.device = device_;
@@ -688,7 +719,7 @@ private:
     uint32_t timeout_ms_ = 30000, ar_seq_ = 0, halo_seq_ = 0;
     int halo_max_ = 8192;
     int tier_ = 0;  // kind of window memory: 0 uncached, 1 fine-grained, 2 plain
-    bool fuse_ = true, halo_ok_ = false;
+    bool fuse_ = true, halo_ok_ = false, bulk_ = false;
     DevBuf<int32_t> err_;
     unsigned long long *ar_own_ = nullptr, *halo_own_ = nullptr;
     unsigned long long *ar_map_[k::kPeerMax], *halo_map_[k::kPeerMax];

@@ -134,6 +134,21 @@ struct PeerHalo {
     int64_t send_off[5], recv_off[5];
     int32_t *err;
 };
+// The same exchange for segments that are bandwidth-bound (a node PLANE of a 3-D slab): the payload
+// goes as plain doubles in chunks of kBulkChunk, each followed -- after a system-scope release -- by
+// ONE flag store; the receiver waits on the flag of a chunk, then copies it out of its staging.
+constexpr int kBulkChunk = 2048;
+struct PeerBulk {
+    int npeers;
+    uint32_t seq, timeout_ms;
+    double *rdata[4];                 // where my segment for peer i starts in its staging
+    unsigned long long *rflag[4];     // that staging's flag of element 0 of my segment (one flag per chunk, at its first element)
+    const double *mdata;              // my staging (this parity)
+    const unsigned long long *mflag;
+    int64_t send_off[5], recv_off[5];
+    int32_t send_chunk0[5], recv_chunk0[5];  // prefix sums of the chunk counts
+    int32_t *err;
+};
 }  // namespace k
 
 // ---------------------------------------------------------------------------
@@ -321,6 +336,7 @@ void gather(const double *x, const int32_t *idx, int64_t n, double *out, const i
 // peer-store collectives (stand-alone launches; the fused forms live in the reducing kernels)
 void peer_allreduce(const PeerAR &a, double *buf, int count, hipStream_t s);
 void peer_exchange(const PeerHalo &h, const double *sendbuf, double *recvbuf, hipStream_t s);
+void peer_exchange_bulk(const PeerBulk &h, const double *sendbuf, double *recvbuf, hipStream_t s);
 // Jacobi / Schur pieces
 void jacobi(const double *dinv, const double *x, double *y, int64_t n, const int32_t *done, hipStream_t s);
 void extract_diag_inv(const CsrDev &A, double *dinv, hipStream_t s);

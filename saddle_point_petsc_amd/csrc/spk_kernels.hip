@@ -1200,6 +1200,66 @@ void peer_exchange(const PeerHalo &h, const double *sendbuf, double *recvbuf, hi
                        sendbuf, recvbuf);
 }
 
+// Bulk form (PeerBulk): one workgroup per chunk of kBulkChunk doubles.  Send workgroups come first in
+// the grid: copy the chunk into the peer's staging, release at system scope, then ONE flag store.
+// Receive workgroups wait for their chunk's flag, acquire, copy the chunk out.
+__global__ __launch_bounds__(kThreads) void peer_exchange_bulk_kernel(PeerBulk h, const double *__restrict__ sendbuf,
+                                                                      double *__restrict__ recvbuf)
+{
+    __shared__ int okf;
+    const int nsend = h.send_chunk0[h.npeers];
+    int b = blockIdx.x;
+    if (b < nsend) {
+        int i = 0;
+        while (i + 1 < h.npeers && b >= h.send_chunk0[i + 1]) ++i;
+        const int64_t e0 = (int64_t)(b - h.send_chunk0[i]) * kBulkChunk;
+        const int64_t len = h.send_off[i + 1] - h.send_off[i];
+        const int64_t n = len - e0 < kBulkChunk ? len - e0 : kBulkChunk;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(sendbuf + h.send_off[i] + e0);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(h.rdata[i] + e0);
+        for (int64_t j = threadIdx.x; j < n; j += kThreads) st_sys(dst + j, src[j]);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) st_sys(h.rflag[i] + e0, (unsigned long long)h.seq);
+        return;
+    }
+    b -= nsend;
+    int i = 0;
+    while (i + 1 < h.npeers && b >= h.recv_chunk0[i + 1]) ++i;
+    const int64_t e0 = h.recv_off[i] + (int64_t)(b - h.recv_chunk0[i]) * kBulkChunk;
+    const int64_t rem = h.recv_off[i + 1] - e0;
+    const int64_t n = rem < kBulkChunk ? rem : kBulkChunk;
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        if (ld_sys(h.mflag + e0) != (unsigned long long)h.seq) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                __builtin_amdgcn_s_sleep(4);
+                if (ld_sys(h.mflag + e0) == (unsigned long long)h.seq) break;
+                if (__hip_atomic_load(h.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                    wall_clock64() - t0 > (unsigned long long)h.timeout_ms * 100000ull) {
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        if (!ok) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        okf = ok;
+    }
+    __syncthreads();
+    if (!okf) return;
+    __threadfence_system();
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(h.mdata + e0);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(recvbuf + e0);
+    for (int64_t j = threadIdx.x; j < n; j += kThreads) dst[j] = ld_sys(src + j);
+}
+void peer_exchange_bulk(const PeerBulk &h, const double *sendbuf, double *recvbuf, hipStream_t s)
+{
+    const int grid = h.send_chunk0[h.npeers] + h.recv_chunk0[h.npeers];
+    if (grid == 0) return;
+    hipLaunchKernelGGL(peer_exchange_bulk_kernel, dim3((unsigned)grid), dim3(kThreads), 0, s, h, sendbuf, recvbuf);
+}
+
 // ---------------------------------------------------------------------------
 // FP32 inner solve: damped-Jacobi Richardson sweeps y <- y + omega D^-1 (x - A y) on the
 // diagonal block, single precision throughout (BASELINE config 5).  The sweep reuses the

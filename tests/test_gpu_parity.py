@@ -730,9 +730,9 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
     the halo rows into them (tests/_peer_worker.py).  Checked per case: every rank holds the same
     scalars bit for bit (same residual history), the result equals the single-rank oracle to the
     usual bars, and with two ranks -- where the host-staged all-reduce adds in the same order -- it
-    is bit-identical to the host-staged run.  halo_max = 100: halo segments beyond 100 doubles take the
-    inner backend's bulk send/recv (what a 3-D node plane does in production) while the all-reduces
-    stay on the windows."""
+    is bit-identical to the host-staged run.  halo_max = 100: with a halo segment beyond 100 doubles the
+    exchange takes the BULK form (plain doubles in chunks + one flag per chunk: what the node plane of
+    a 3-D slab does in production) instead of granules."""
     _launch_peer_worker(tmp_path, P, "cases", 29650 + P + (10 if halo_max else 0),
                         {"SPK_PEER_HALO_MAX": halo_max} if halo_max else None)
     R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
