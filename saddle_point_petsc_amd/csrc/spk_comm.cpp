@@ -385,6 +385,7 @@ public:
                 close_maps(ar_map_, ar_own_);
                 if (ar_own_) (void)hipFree(ar_own_);
                 ar_own_ = nullptr;
+                (void)hipGetLastError();
                 SPK_HIP(hipMemset(err_.p, 0, sizeof(int32_t)));
             }
         }
@@ -712,6 +713,7 @@ private:
             }
             map[p] = nullptr;
         }
+        (void)hipGetLastError();  // a failed close must not surface later as somebody else's launch error
     }
 
     std::unique_ptr<Comm> inner_;
