@@ -66,11 +66,12 @@ def spmv_bytes(nrows, nnz):
 
 def iteration_bytes(n, nnz, nnzB, restart, m=4):
     """Algorithmic bytes of ONE average FGMRES(restart) iteration of the fused
-    Schur path, vec = 8n bytes, j_avg basis vectors:
-      fused scale+PC : w', dinv, m rows of B D in; v, z, c out      (5 + m) vec
+    Schur path, vec = 8n bytes, j_avg basis vectors,
+    m = planes of B D streamed per pass (spk_get_bd_planes):
+      fused scale+PC : w', dinv, m planes of B D in; v, z, c out    (5 + m) vec
       SpMV (y += Ax) : 12 nnz + 4 n + x + y in + y out
       MDot           : V_0..V_j and w                               (j + 2) vec
-      MAXPY + norms  : V_0..V_j, w in/out, m rows of B D            (j + 3 + m) vec
+      MAXPY + norms  : V_0..V_j, w in/out, m planes of B D          (j + 3 + m) vec
       per cycle      : x += Z y, true residual (unfused K x, 3 vec) / restart"""
     vec = 8 * n
     j_avg = (restart - 1) / 2.0
@@ -282,7 +283,7 @@ def main():
 
     its_per_s = args.steps / elapsed
     nnzB_local = B.nnz if saddle else 0
-    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, B.nrows) \
+    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, ctx.bd_planes() or B.nrows) \
         if (saddle and args.inner_sweeps == 0) else None
     out = {
         "metric": METRIC,

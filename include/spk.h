@@ -194,6 +194,10 @@ int spk_pc_set_inner(spk_ctx *ctx, int sweeps, double omega);
 /* Copies S^ (m doubles) to the host, for inspection. */
 int spk_get_schur_diag(spk_ctx *ctx, double *shat);
 int spk_get_jacobi_diag(spk_ctx *ctx, double *dinv /* n_local */);
+/* Dense planes of B diag(A)^-1 the fused Schur kernels stream per pass: m, or m/2 when rows 2q / 2q+1
+ * live on even / odd vector entries (x / y degrees of freedom of a dof-2 grid) and share a plane;
+ * 0 when the fused path is not set up.  For byte models. */
+int spk_get_bd_planes(const spk_ctx *ctx, int32_t *planes);
 
 /* ---- the three plug points ------------------------------------------------ */
 /* MATSHELL:  y = K x.   PCSHELL: y = M^-1 x.   Lengths n_local + m. */

@@ -86,6 +86,7 @@ def _load():
     L.spk_pc_set_inner.argtypes = [vp, C.c_int, C.c_double]
     L.spk_get_schur_diag.argtypes = [vp, f64p]
     L.spk_get_jacobi_diag.argtypes = [vp, f64p]
+    L.spk_get_bd_planes.argtypes = [vp, C.POINTER(i32)]
     L.spk_mult.argtypes = [vp, f64p, f64p, C.c_int]
     L.spk_pc_apply.argtypes = [vp, f64p, f64p, C.c_int]
     L.spk_fgmres.argtypes = [vp, f64p, f64p, C.c_int, C.POINTER(Opts), C.POINTER(Result), vp, i32]

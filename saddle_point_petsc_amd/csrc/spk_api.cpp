@@ -206,6 +206,13 @@ int spk_get_jacobi_diag(spk_ctx *c, double *dinv)
     SPK_CATCH(c)
 }
 
+int spk_get_bd_planes(const spk_ctx *c, int32_t *planes)
+{
+    if (!c || !planes) return SPK_ERR_ARG;
+    *planes = !c->bd.p ? 0 : (c->bd_packed ? c->m / 2 : c->m);
+    return SPK_OK;
+}
+
 int spk_get_sizes(const spk_ctx *c, int64_t *n_global, int32_t *n_local, int32_t *m, int64_t *nnz_local,
                   int32_t *n_ghost)
 {

@@ -307,7 +307,8 @@ void scatter_row(const int32_t *colidx, const double *val, int k0, int k1, const
 void sum_slots(const double *slots, int nslots, int ld, int count, double *out, hipStream_t s);
 // f.out[i] = V_i . w for i < nv, then V2_i . w for i < nv2 (second slab, same stride), then w.w
 void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
-          const Finish &f, const int32_t *done, hipStream_t s, const double *V2 = nullptr, int nv2 = 0);
+          const Finish &f, const int32_t *done, hipStream_t s, const double *V2 = nullptr, int nv2 = 0,
+          int v2_split = 0);
 // single-reduction Gram-Schmidt: scalars derived by workgroup 0 of the MAXPY kernel
 struct PythArgs {
     int m;               // < 0: off
@@ -321,8 +322,11 @@ struct PythArgs {
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
            const int32_t *done, hipStream_t s, const double *bd = nullptr, int64_t ldb = 0, int64_t n_bd = 0, int m = 0,
-           double *w1side = nullptr, const PythArgs *pyth = nullptr);
+           double *w1side = nullptr, const PythArgs *pyth = nullptr, int bd_packed = 0);
 void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *bd, hipStream_t s);
+// rows 2q, 2q+1 of B D interleaved by parity into one plane each (bd_packed = 1 in the kernels that
+// stream them); *bad != 0: the rows do not have that structure
+void pack_bd(const double *bd, int64_t ldb, int64_t n, int m, double *bdp, int32_t *bad, hipStream_t s);
 void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
                double *w1side, const Finish &f, const int32_t *done, hipStream_t s);
 // x *= *alpha_dev
@@ -376,13 +380,14 @@ void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const do
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
                 const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
-                const SendRanges *sr = nullptr);
+                const SendRanges *sr = nullptr, int bd_packed = 0);
 // single-reduction mode: MAXPY of iteration loc + head of iteration loc+1 + Givens of iteration loc
 // in one pass (dots = reduced [h, B D w, w.w]; tb = B D v_i per basis vector, (restart+2) x 8)
 void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double *tb, double *nrm_out, double *w,
                 const double *dinv, const double *bd, int64_t ldb, const double *shat, const double *gram, int fact,
                 int64_t nl, int m, double *z, double *c, double *w1side, const double *wl_in, double *wl_out,
-                const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *sr = nullptr);
+                const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *sr = nullptr,
+                int bd_packed = 0);
 void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)
@@ -433,6 +438,8 @@ struct spk_ctx {
     bool pc_ready = false;
     spk::DevBuf<double> dinv, shat, gram;  // n_local, m, m*m
     spk::DevBuf<double> bd;                // the m rows of B D as dense vectors of stride ld (fused Schur path)
+    spk::DevBuf<double> bdpk;              // the same as m/2 parity-interleaved planes, when the rows allow
+    bool bd_packed = false;
     // FP32 inner solve (0 sweeps = plain diag(A)^-1)
     int inner_sweeps = 0;
     double inner_omega = 1.0;

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                                                  const double *__restrict__ w, int64_t n2,
                                                  int64_t n_dot, double *__restrict__ partials,
                                                  int with_ww,
-                                                 double *__restrict__ out, PeerAR ar,
+                                                 double *__restrict__ out, PeerAR ar, int split,
                                                  const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -630,8 +630,10 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                     // vector tile: the group stays branch-free and costs no bandwidth
                     const bool live = g0 + v < nv;
                     const int ic = live ? g0 + v : 0;
-                    // vectors nv1.. come from a second slab (the rows of B D in the single-reduction mode)
-                    const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(ic - nv1) * ldv);
+                    // vectors nv1.. come from a second slab (the rows of B D in the single-reduction mode);
+                    // split: that slab holds parity-interleaved planes, "vector" j is half j & 1 of plane j / 2
+                    const int j2 = ic - nv1;
+                    const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(split ? j2 >> 1 : j2) * ldv);
 #pragma unroll
                     for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, live ? idx[u] : 0);
                 }
@@ -639,8 +641,18 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                 for (int v = 0; v < G; ++v) {
                     const double mk = (g0 + v < nv) ? 1.0 : 0.0;
                     double d = 0.0;
+                    if (split && g0 + v >= nv1 && g0 + v < nv) {  // wave-uniform
+                        if ((g0 + v - nv1) & 1) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                            for (int u = 0; u < U; ++u) d += a[v][u].y * wv[u].y;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                    }
                     acc[g0 + v] += mk * d;
                 }
             }
@@ -691,7 +703,7 @@ __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__
                                                       const double *__restrict__ V2, int nv1,
                                                       const double *__restrict__ w, int64_t n2, int64_t n_dot,
                                                       double *__restrict__ partials, int with_ww, double *__restrict__ out,
-                                                      PeerAR ar, const int32_t *__restrict__ done)
+                                                      PeerAR ar, int split, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     __shared__ double lds[256];
@@ -730,16 +742,28 @@ __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__
                 for (int v = 0; v < G; ++v) {
                     const bool live = g0 + v < cnt;
                     const int ic = v0 + (live ? g0 + v : 0);
-                    const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(ic - nv1) * ldv);
+                    const int j2 = ic - nv1;  // split: "vector" j2 of the second slab is half j2 & 1 of plane j2 / 2
+                    const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(split ? j2 >> 1 : j2) * ldv);
 #pragma unroll
                     for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, live ? idx[u] : 0);
                 }
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
                     const double mk = (g0 + v < cnt) ? 1.0 : 0.0;
+                    const int ic = v0 + g0 + v;
                     double d = 0.0;
+                    if (split && ic >= nv1 && g0 + v < cnt) {  // wave-uniform
+                        if ((ic - nv1) & 1) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                            for (int u = 0; u < U; ++u) d += a[v][u].y * wv[u].y;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                    }
                     acc[g0 + v] += mk * d;
                 }
             }
@@ -817,10 +841,10 @@ static int vec_grid(int64_t n2, int T = kVT)
 template <int T, int U, int G>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *V2, int nv1,
                         const double *w, int64_t n2, int64_t n_dot, double *pp, int last, double *oo,
-                        const PeerAR &ar, const int32_t *done)
+                        const PeerAR &ar, int split, const int32_t *done)
 {
 #define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, G, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
-                                         n2, n_dot, pp, last, oo, ar, done)
+                                         n2, n_dot, pp, last, oo, ar, split, done)
     switch (ng) {
     case 1: SPK_MDOT(1); break;
     case 2: SPK_MDOT(2); break;
@@ -832,8 +856,10 @@ static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64
 }
 
 void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int64_t n_dot,
-          const Finish &f, const int32_t *done, hipStream_t s, const double *V2, int nv2)
+          const Finish &f, const int32_t *done, hipStream_t s, const double *V2, int nv2, int split)
 {
+    // split: V2 holds nv2 / 2 parity-interleaved planes (pack_bd); result nv + j is half j & 1 of plane j / 2
+    if (split && nv + nv2 > 40) fail(SPK_ERR_ARG, "mdot: split planes need one launch (<= 40 vectors)");
     // nv vectors from V, then nv2 from V2 (same stride); results in that order, w.w last
     const int ntot = nv + nv2;
     if (ntot > kMaxNv - 1) fail(SPK_ERR_ARG, "mdot: %d vectors exceed %d", ntot, kMaxNv - 1);
@@ -855,7 +881,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         const WsShape ws = ws_shape(n2);
         if (ws.on) {
 #define SPK_MDOT_WS(VW, UU, GG) hipLaunchKernelGGL((mdot_ws_kernel<VW, UU, GG, true>), dim3(ws.grid), dim3(256), 0, s, Vp, ldv, cnt, \
-                                                   V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, done)
+                                                   V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, done)
 #define SPK_MDOT_WS_U(VW) do { if (ws.U == 8) SPK_MDOT_WS(VW, 8, 2); else if (ws.U == 4) SPK_MDOT_WS(VW, 4, 4); else SPK_MDOT_WS(VW, 2, 4); } while (0)
             const int per = (cnt + 3) / 4;
             if (per <= 4) SPK_MDOT_WS_U(4);
@@ -866,7 +892,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
             v0 += 40;
             continue;
         }
-#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, done
+#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, done
         if (vs.T == 512) mdot_launch<512, 4, 4>(SPK_MDOT_ARGS);
         else if (vs.U == 4) mdot_launch<256, 4, 4>(SPK_MDOT_ARGS);
         else if (vs.U == 2 && vs.G == 8) mdot_launch<256, 2, 8>(SPK_MDOT_ARGS);
@@ -892,7 +918,8 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          double *__restrict__ out,
                                                          const double *__restrict__ bd, int64_t ldb,
                                                          int64_t n_bd, int m, double *__restrict__ w1side,
-                                                         PythArgs py, PeerAR ar, const int32_t *__restrict__ done)
+                                                         PythArgs py, PeerAR ar, int packed,
+                                                         const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     if (nv_dev) nv = *nv_dev;
@@ -983,6 +1010,23 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
         if (MP > 0 && bd) {
             // traw[r] += (B D)_r . w_new over the u rows; B D is stored PLANAR (row r = one dense
             // vector of stride ldb), so these are m more perfectly coalesced streams
+            if (packed) {  // m/2 parity-interleaved planes: .x belongs to row 2q, .y to row 2q+1
+#pragma unroll
+                for (int q = 0; q < MP / 2; ++q) {
+                    if (2 * q < m) {
+                        double2 e[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) e[u] = ld2s<NT>(bd + (size_t)q * ldb, idx[u]);
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (ok[u]) {
+                                if (2 * idx[u] < n_bd) tacc[2 * q] += e[u].x * wv[u].x;
+                                if (2 * idx[u] + 1 < n_bd) tacc[2 * q + 1] += e[u].y * wv[u].y;
+                            }
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < MP; ++r) {
                 if (r < m) {
@@ -997,6 +1041,7 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                         }
                     }
                 }
+            }
             }
         }
     }
@@ -1029,10 +1074,10 @@ template <int T, int U, int G>
 static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64_t ldv, int nv, const int32_t *nv_dev,
                          const double *a, double sign, double *w, int64_t n2, int64_t n_dot, const Finish &f,
                          const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side, const PythArgs &py,
-                         const int32_t *done)
+                         int packed, const int32_t *done)
 {
 #define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, G, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          sign, w, n2, n_dot, f.partials, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, done)
+                                          sign, w, n2, n_dot, f.partials, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, packed, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
     else SPK_MAXPY(0);
@@ -1042,7 +1087,7 @@ static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64
 void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const double *a,
            double coef_sign, double *w, int64_t n, int64_t n_dot, const Finish &f,
            const int32_t *done, hipStream_t s, const double *bd, int64_t ldb, int64_t n_bd, int m, double *w1side,
-           const PythArgs *pyth)
+           const PythArgs *pyth, int packed)
 {
     const int64_t n2 = (n + 1) / 2;
     const VecShape vs = vec_shape(n2, true);
@@ -1051,7 +1096,7 @@ void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const do
     if (pyth) py = *pyth;
     // MP > 0 also switches on the lambda side copy; in single-reduction mode bd is not read
     const int mp = ((bd || pyth) && m > 0) ? (m <= 4 ? 4 : 8) : 0;
-#define SPK_MAXPY_ARGS mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, done
+#define SPK_MAXPY_ARGS mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, packed, done
     if (vs.T == 512) maxpy_launch<512, 4, 4>(SPK_MAXPY_ARGS);
     else if (vs.U == 4) maxpy_launch<256, 4, 4>(SPK_MAXPY_ARGS);
     else if (vs.U == 2 && vs.G == 8) maxpy_launch<256, 2, 8>(SPK_MAXPY_ARGS);
@@ -1555,6 +1600,29 @@ void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *
                        Bt.rowptr.p, Bt.colidx.p, Bt.val.p, Bt.nrows, dinv, m, ldb, bd);
 }
 
+// Rows 2q and 2q+1 of B D often have DISJOINT support by parity -- row 2q lives on even vector entries
+// (the x degrees of freedom of a dof-2 grid), row 2q+1 on odd ones (y): half of each dense row is
+// zeros.  Then the two rows share one plane, bdp[q][i] = i even ? bd[2q][i] : bd[2q+1][i]: a double2
+// load delivers (row 2q, row 2q+1) and the kernels stream m/2 planes instead of m.  Adding the
+// products of the stored zeros changed nothing, so every sum keeps its bits.  *bad is raised when
+// the structure does not hold (the dense rows are used then).
+__global__ __launch_bounds__(kThreads) void pack_bd_kernel(const double *__restrict__ bd, int64_t ldb, int64_t n, int m,
+                                                           double *__restrict__ bdp, int32_t *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    for (int q = 0; 2 * q + 1 < m; ++q) {
+        const double a = bd[(size_t)(2 * q) * ldb + i], b = bd[(size_t)(2 * q + 1) * ldb + i];
+        if ((i & 1) ? a != 0.0 : b != 0.0) *bad = 1;
+        bdp[(size_t)q * ldb + i] = (i & 1) ? b : a;
+    }
+}
+void pack_bd(const double *bd, int64_t ldb, int64_t n, int m, double *bdp, int32_t *bad, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(pack_bd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, bd, ldb, n, m, bdp, bad);
+}
+
 // out[0] = r.r (first n_dot entries), out[1+q] = sum_i (B D)[i][q] r_i : cycle start of the fused path
 template <int MP>
 __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict__ x, int64_t n2, int64_t n_dot,
@@ -1820,8 +1888,9 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
     const double *__restrict__ dinv, const double *__restrict__ bd, int64_t ldb,
     const double *__restrict__ shat, const double *__restrict__ gram, int fact, int64_t nl, int m,
     double *__restrict__ z, double *__restrict__ c, KrylovArrays ka, int loc_prev,
-    const double *__restrict__ dots_prev, SendRanges sr, const int32_t *__restrict__ done)
+    const double *__restrict__ dots_prev, SendRanges sr, int packed, const int32_t *__restrict__ done)
 {
+    // packed: bd holds m/2 parity-interleaved planes (pack_bd_kernel) instead of m dense rows
     // c == nullptr: Jacobi head (K = A, m = 0): v = w'/||w'||, z = D v, nothing pre-loaded
     if (*done) return;
     __shared__ double ys[MP], xs[MP], ts[MP];
@@ -1886,12 +1955,23 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
         w.x *= inv_tt;
         w.y *= inv_tt;
         double s0 = 0.0, s1 = 0.0;
+        if (packed) {
 #pragma unroll
-        for (int r = 0; r < MP; ++r) {
-            if (r < m) {
-                const double2 e = ld2s<true>(bd + (size_t)r * ldb, i);
-                s0 += e.x * yv[r];
-                s1 += e.y * yv[r];
+            for (int q = 0; q < MP / 2; ++q) {
+                if (2 * q < m) {
+                    const double2 e = ld2s<true>(bd + (size_t)q * ldb, i);
+                    s0 += e.x * yv[2 * q];
+                    s1 += e.y * yv[2 * q + 1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < MP; ++r) {
+                if (r < m) {
+                    const double2 e = ld2s<true>(bd + (size_t)r * ldb, i);
+                    s0 += e.x * yv[r];
+                    s1 += e.y * yv[r];
+                }
             }
         }
         double2 zz, cc;
@@ -1934,7 +2014,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
                 const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
-                const SendRanges *srp)
+                const SendRanges *srp, int packed)
 {
     const int64_t n2 = nl / 2;
     int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
@@ -1945,10 +2025,10 @@ void fused_head(double *v, const double *nrm, const double *w1raw, const double 
     if (sr.peer) grid += (2 * sr.nrecv + kThreads - 1) / kThreads;  // the waiting workgroups come last
     if (m <= 4)
         hipLaunchKernelGGL(fused_head_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
-                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, done);
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, packed, done);
     else
         hipLaunchKernelGGL(fused_head_kernel<8>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
-                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, done);
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, packed, done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1971,7 +2051,7 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
     const double *__restrict__ bd, int64_t ldb, const double *__restrict__ shat, const double *__restrict__ gram,
     int fact, int64_t nl, int m, double *__restrict__ z, double *__restrict__ c, double *__restrict__ w1side,
     const double *__restrict__ wl_in, double *__restrict__ wl_out, KrylovArrays ka, int loc, SendRanges sr,
-    const int32_t *__restrict__ done)
+    int packed, const int32_t *__restrict__ done)
 {
     // wl_in: the m lambda entries of w (= what the previous head wrote into c[nl..]; the SpMV does not
     // touch them) as a side copy -- workgroup 0 overwrites w[nl..] with the normalised entries while the
@@ -2069,14 +2149,28 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
             dv[u] = ld2(dinv, idx[u]);
             sv[u].x = sv[u].y = 0.0;
         }
+        if (packed) {
 #pragma unroll
-        for (int r = 0; r < MP; ++r) {
-            if (r < m) {
+            for (int q = 0; q < MP / 2; ++q) {
+                if (2 * q < m) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const double2 e = ld2s<true>(bd + (size_t)r * ldb, idx[u]);
-                    sv[u].x += e.x * yv[r];
-                    sv[u].y += e.y * yv[r];
+                    for (int u = 0; u < U; ++u) {
+                        const double2 e = ld2s<true>(bd + (size_t)q * ldb, idx[u]);
+                        sv[u].x += e.x * yv[2 * q];
+                        sv[u].y += e.y * yv[2 * q + 1];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < MP; ++r) {
+                if (r < m) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const double2 e = ld2s<true>(bd + (size_t)r * ldb, idx[u]);
+                        sv[u].x += e.x * yv[r];
+                        sv[u].y += e.y * yv[r];
+                    }
                 }
             }
         }
@@ -2147,7 +2241,7 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
 void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double *tb, double *nrm_out, double *w,
                 const double *dinv, const double *bd, int64_t ldb, const double *shat, const double *gram, int fact,
                 int64_t nl, int m, double *z, double *c, double *w1side, const double *wl_in, double *wl_out,
-                const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *srp)
+                const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *srp, int packed)
 {
     const int64_t n2 = nl / 2;
     SendRanges sr{};
@@ -2161,7 +2255,7 @@ void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double
     grid += 1;
     if (sr.peer) grid += (2 * sr.nrecv + T - 1) / T;
 #define SPK_MH(TT, GG, UU, MPP) hipLaunchKernelGGL((maxpy_head_kernel<TT, GG, UU, MPP>), dim3(grid), dim3(TT), 0, s, V, ldv, nv, dots, tb, \
-                                                   nrm_out, w, dinv, bd, ldb, shat, gram, fact, nl, m, z, c, w1side, wl_in, wl_out, ka, loc, sr, done)
+                                                   nrm_out, w, dinv, bd, ldb, shat, gram, fact, nl, m, z, c, w1side, wl_in, wl_out, ka, loc, sr, packed, done)
     if (m <= 4) {
         if (!thin) SPK_MH(512, 4, 4, 4);
         else if (U == 2) SPK_MH(256, 8, 2, 4);

@@ -383,6 +383,20 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
         c->n_local % 2 == 0 && c->inner_sweeps == 0) {
         c->bd.alloc((size_t)c->ld * m, 16);
         k::build_bd(c->Bt, c->dinv.p, m, c->ld, c->bd.p, s);
+        // rows 2q / 2q+1 on even / odd entries (x / y degrees of freedom): m/2 planes instead of m rows
+        c->bdpk.release();
+        c->bd_packed = false;
+        if (m % 2 == 0 && !getenv("SPK_BD_DENSE")) {
+            c->bdpk.alloc((size_t)c->ld * (m / 2), 16);
+            DevBuf<int32_t> bad;
+            bad.alloc(1);
+            k::pack_bd(c->bd.p, c->ld, c->n_local, m, c->bdpk.p, bad.p, s);
+            int32_t hb = 1;
+            SPK_HIP(hipMemcpyAsync(&hb, bad.p, sizeof hb, hipMemcpyDeviceToHost, s));
+            SPK_HIP(hipStreamSynchronize(s));
+            c->bd_packed = hb == 0;
+            if (!c->bd_packed) c->bdpk.release();
+        }
     }
     SPK_HIP(hipStreamSynchronize(s));
     c->pc_type = pc_type;
@@ -567,7 +581,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                         c->inner_sweeps == 0;
     const bool head = fused || fusedj;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
-    const double *bdp = fused ? c->bd.p : nullptr;
+    const int bpk = fused && c->bd_packed ? 1 : 0;   // B D as m/2 parity-interleaved planes
+    const double *bdp = fused ? (bpk ? c->bdpk.p : c->bd.p) : nullptr;
     // single-reduction Gram-Schmidt (fused CGS without refinement): h = V^T w, q = B D w and w.w
     // come out of ONE pass and ONE all-reduce; ||w'||^2 = w.w - |h|^2 and B D w' = q - sum h_i B D v_i
     // follow without touching w' -- one collective per iteration instead of two.
@@ -606,9 +621,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 bool inhead = prev_inhead;
                 if (!head_done) {
                     inhead = packed && c->comm->fused_halo(sr, c->xghost.p);   // ... or does the whole exchange
-                    k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, c->bd.p, ld, c->shat.p, c->gram.p,
+                    k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, bdp, ld, c->shat.p, c->gram.p,
                                   c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
-                                  packed ? &sr : nullptr);
+                                  packed ? &sr : nullptr, bpk);
                     last = loc;
                     if (single) k::copy_small(w + nl, wl(loc), m, done, s);
                 }
@@ -641,12 +656,14 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     c->comm->allreduce_sum(db + j, 1, s);
                     const bool lastv = j == loc;
                     k::maxpy(Vj(j), ld, 1, nullptr, db + j, -1.0, w, N, n_dot, c->fin(lastv ? nb : nullptr), done, s,
-                             lastv ? bdp : nullptr, ld, nl, m, lastv && fused ? w1side : nullptr);
+                             lastv ? bdp : nullptr, ld, nl, m, lastv && fused ? w1side : nullptr, nullptr, bpk);
                 }
                 c->comm->allreduce_sum(nb, nn, s);
             } else if (single) {
                 const k::PeerAR ar = loc + 1 + m <= 40 ? c->comm->fused_allreduce(loc + 2 + m) : k::PeerAR{};
-                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, c->bd.p, m);
+                // B D w from the same pass: the dense rows, or two halves per parity-interleaved plane
+                const bool spl = bpk && loc + 1 + m <= 40;
+                k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, spl ? c->bdpk.p : c->bd.p, m, spl ? 1 : 0);
                 if (!ar.P) c->comm->allreduce_sum(db, loc + 2 + m, s);
                 if (loc + 1 < mk) {
                     k::SendRanges sr = c->send_ranges;
@@ -655,7 +672,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     const k::SendRanges *srp = sr.n > 0 && (fused || prev_inhead) ? &sr : nullptr;
                     k::maxpy_head(V, ld, loc + 1, db, c->ka.tb, nb, w, c->dinv.p, bdp, ld, c->shat.p, c->gram.p,
                                   fused ? c->schur_fact : SPK_SCHUR_LOWER, nl, m, Zj(loc + 1), fused ? Vj(loc + 2) : nullptr,
-                                  w1side, wl(loc), wl(loc + 1), c->ka, loc, done, s, srp);
+                                  w1side, wl(loc), wl(loc + 1), c->ka, loc, done, s, srp, bpk);
                     head_done = true;
                     last = -1;  // its Givens step is done
                 } else {
@@ -673,7 +690,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 if (!ar1.P) c->comm->allreduce_sum(db, loc + 2, s);
                 const k::PeerAR ar2 = c->comm->fused_allreduce(nn);
                 k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nb, ar2), done, s, bdp, ld, nl, m,
-                         fused ? w1side : nullptr);
+                         fused ? w1side : nullptr, nullptr, bpk);
                 if (!ar2.P) c->comm->allreduce_sum(nb, nn, s);
                 if (o.cgs_refine != SPK_REFINE_NEVER) {
                     // second pass on the device's own decision (-ksp_gmres_cgs_refinement_type)
@@ -682,7 +699,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(sm2), skip, s);
                     c->comm->allreduce_sum(sm2, loc + 2, s);
                     k::maxpy(V, ld, loc + 1, nullptr, sm2, -1.0, w, N, n_dot, c->fin(nrm2b), skip, s, bdp, ld, nl, m,
-                             fused ? w1side : nullptr);
+                             fused ? w1side : nullptr, nullptr, bpk);
                     c->comm->allreduce_sum(nrm2b, nn, s);
                     k::krylov_refine_merge(c->ka, loc, db, sm2, nb, nrm2b, nn, s);
                 }

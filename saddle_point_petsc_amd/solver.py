@@ -157,6 +157,11 @@ class Context:
         self._chk(lib.spk_get_schur_diag(self.h, out))
         return out
 
+    def bd_planes(self):
+        v = C.c_int32()
+        self._chk(lib.spk_get_bd_planes(self.h, C.byref(v)))
+        return v.value
+
     def jacobi_diag(self):
         out = np.zeros(self.sizes()["n_local"])
         self._chk(lib.spk_get_jacobi_diag(self.h, out))
