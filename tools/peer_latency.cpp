@@ -1,7 +1,8 @@
 // Development probe: latency of the granule all-reduce / halo kernels between P "ranks" that are P
 // non-blocking streams of ONE process on one GPU (run with GPU_MAX_HW_QUEUES=8 so that every
 // stream owns a hardware queue).  What it measures is launch + store + poll on one chip; xGMI adds
-// its flight time on top.  Build: see tools/Makefile target peer_latency.
+// its flight time on top.  Build: hipcc -O2 -std=c++17 --offload-arch=gfx950 tools/peer_latency.cpp -o tools/peer_latency
+// -Lsaddle_point_petsc_amd -lspk -Wl,-rpath,'$ORIGIN/../saddle_point_petsc_amd'
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
