@@ -227,7 +227,10 @@ def main():
         dist.all_reduce(t)
         r2 = float(t.item())
     true_rnorm = float(np.sqrt(r2))
-    residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= 1e-6 * max(true_rnorm, 1e-300))
+    # (below ~1e-11 of the initial residual the true residual sits on its round-off floor while the
+    # recurrence keeps falling: both "converged", not comparable digit by digit)
+    residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= 1e-6 * max(true_rnorm, 1e-300) or
+                       max(true_rnorm, info["rnorm"]) <= 1e-11 * info["rnorm0"])
 
     # ---- the opt-in single-reduction mode on the same K iterations (one all-reduce and three launches
     # per iteration instead of two and four; ||w'||^2 by Pythagoras, see include/spk.h).  Reported
