@@ -47,6 +47,27 @@ def main():
         dist.destroy_process_group()
         return
 
+    if mode == "reset":
+        # KSPSetOperators twice on ONE context: the halo staging is re-allocated and re-shared
+        # (collectively), the all-reduce windows stay
+        c = S.Context(0)
+        c.comm_init_torch(dist, rank, world)
+        assert c.comm_enable_peer(), c.last_error()
+        for it, (mx, my) in enumerate([(20, 18), (28, 33), (20, 18)]):
+            b, e = S.partition_slab(mx, my, rank, world)
+            A, f = S.AssembleOperator_Laplace(mx, my, b, e)
+            Bs, g = S.AssembleOperator_Constraints(mx, my, b, e)
+            c.set_block(S.BLOCK_A00, A)
+            c.set_block(S.BLOCK_A10, Bs)
+            c.pc_setup(S.PC_SCHUR, S.SCHUR_FULL)
+            x, info = c.fgmres(np.concatenate([f, g]), rtol=1e-9)
+            res[f"{it}/x"], res[f"{it}/meta"] = x, np.array([b, e, info["its"], info["reason"]], np.int64)
+        c.close()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     # (name, dim, grid, pc, fact, inner sweeps, fused); solver options by name suffix, see OPTS
     OPTS = {"single": dict(single_reduce=1), "mgs": dict(orthog=1), "refine": dict(cgs_refine=1),
             "r62": dict(restart=62), "guess": dict()}

@@ -784,6 +784,26 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
                 assert np.array_equal(a, b_), name
 
 
+def test_peer_store_operators_set_again(spk, oracle, tmp_path):
+    """KSPSetOperators three times on one context with the peer-store backend on (different grid,
+    then the first one again): the halo staging follows the new plan each time."""
+    P = 2
+    _launch_peer_worker(tmp_path, P, "reset", 29671)
+    R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
+    for it, (mx, my) in enumerate([(20, 18), (28, 33), (20, 18)]):
+        A, f = spk.AssembleOperator_Laplace(mx, my)
+        B, g = spk.AssembleOperator_Constraints(mx, my)
+        rhs = np.concatenate([f, g])
+        xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-9)
+        x = np.zeros(A.nrows + 4)
+        for r in range(P):
+            b, e, its, reason = R[r][f"{it}/meta"]
+            assert reason == 2 and abs(its - io["its"]) <= 1
+            x[b:e], x[A.nrows:] = R[r][f"{it}/x"][:e - b], R[r][f"{it}/x"][-4:]
+        assert relerr(x, xo) < 1e-7
+    assert np.array_equal(R[0]["0/x"], R[0]["2/x"])        # same operators again: same bits
+
+
 def test_peer_store_wait_is_bounded(spk, tmp_path):
     """A rank that never arrives must turn into SPK_ERR_COMM, not into a kernel that spins for ever:
     rank 0 multiplies (halo exchange + all-reduce) while rank 1 stays away."""
