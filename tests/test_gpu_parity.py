@@ -723,8 +723,8 @@ def _launch_peer_worker(tmp_path, P, mode, port, env_extra=None, timeout=280):
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
 
 
-@pytest.mark.parametrize("P,halo_max", [(2, None), (3, None), (2, "100")])
-def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_max):
+@pytest.mark.parametrize("P,halo_max,fuse", [(2, None, "1"), (3, None, "1"), (2, "100", "1"), (3, None, "0")])
+def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_max, fuse):
     """P PROCESSES on this GPU, each owning a row slab; the peer-store backend maps the other
     processes' windows through HIP IPC and the solver's own kernels write the Krylov all-reduces and
     the halo rows into them (tests/_peer_worker.py).  Checked per case: every rank holds the same
@@ -733,8 +733,10 @@ def test_peer_store_collectives_across_processes(spk, oracle, tmp_path, P, halo_
     is bit-identical to the host-staged run.  halo_max = 100: with a halo segment beyond 100 doubles the
     exchange takes the BULK form (plain doubles in chunks + one flag per chunk: what the node plane of
     a 3-D slab does in production) instead of granules."""
-    _launch_peer_worker(tmp_path, P, "cases", 29650 + P + (10 if halo_max else 0),
-                        {"SPK_PEER_HALO_MAX": halo_max} if halo_max else None)
+    env = {"SPK_PEER_FUSE": fuse}      # "0": every collective as a launch of its own (granule kernels)
+    if halo_max:
+        env["SPK_PEER_HALO_MAX"] = halo_max
+    _launch_peer_worker(tmp_path, P, "cases", 29650 + P + (10 if halo_max else 0) + (20 if fuse == "0" else 0), env)
     R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
     okws = {"mgs": dict(orthog=1), "refine": dict(refine=1), "r62": dict(restart=62)}
     cases = [("schur_full", 2, (24, 26), oracle.PC_SCHUR, 3, 0), ("schur_full_single", 2, (24, 26), oracle.PC_SCHUR, 3, 0),
