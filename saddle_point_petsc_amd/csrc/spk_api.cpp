@@ -97,9 +97,6 @@ int spk_destroy(spk_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     }
     c->comm.reset();
-    if (c->st_pin) (void)hipHostFree(c->st_pin);
-    for (hipEvent_t e : c->st_ev)
-        if (e) (void)hipEventDestroy(e);
     hipStream_t s = c->stream;
     delete c;  // DevBuf destructors free device memory
     if (s) (void)hipStreamDestroy(s);

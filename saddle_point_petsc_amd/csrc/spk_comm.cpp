@@ -583,7 +583,6 @@ public:
         sr.err = err_.p;
         return true;
     }
-    const int32_t *error_word_dev() const override { return err_.p; }
     void check(hipStream_t s) override
     {
         (void)s;

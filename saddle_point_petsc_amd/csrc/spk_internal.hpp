@@ -174,9 +174,6 @@ public:
     virtual bool fused_halo(k::SendRanges &sr, double *xghost) { (void)sr; (void)xghost; return false; }
     // throws SPK_ERR_COMM when a device-side wait of this backend has timed out (call after a sync)
     virtual void check(hipStream_t s) { (void)s; }
-    // device word that is non-zero once such a wait has timed out (nullptr: backend has none); lets a
-    // caller poll it with an asynchronous copy instead of the synchronous check()
-    virtual const int32_t *error_word_dev() const { return nullptr; }
     virtual const char *name() const { return "self"; }
     // in-place sum over ranks of `count` doubles in device memory, stream-ordered
     virtual void allreduce_sum(double *dev, int count, hipStream_t s) { (void)dev; (void)count; (void)s; }
@@ -461,9 +458,6 @@ struct spk_ctx {
     spk::DevBuf<double> kry_d;  // H, cc, ss, rs, nrs, hcol, hist
     spk::DevBuf<spk::KrylovState> kst;
     spk::k::KrylovArrays ka{};
-    // the host reads the state of cycle k while cycle k+1 is already enqueued: pinned copies + events
-    spk::KrylovState *st_pin = nullptr;   // [2], followed by two int32 copies of the comm error word
-    hipEvent_t st_ev[2] = {nullptr, nullptr};
 
     // staging for host-pointer entry points
     spk::DevBuf<double> stage_x, stage_y;

@@ -593,10 +593,6 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                         o.single_reduce == 1 && mk + c->m <= k::kMaxNv - 1;
 
     c->ka.tentative = single ? 1 : 0;
-    if (!c->st_pin) {
-        SPK_HIP(hipHostMalloc((void **)&c->st_pin, 2 * sizeof(KrylovState) + 2 * sizeof(int32_t), hipHostMallocDefault));
-        for (hipEvent_t &e : c->st_ev) SPK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     KrylovState st{};
     int cycles = 0;
     for (;;) {
@@ -728,36 +724,12 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         op_mult(c, x, c->tmp.p, done);
         k::axpby(1.0, b, 0.0, Vj(0), N, done, s);
         k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, done, s);
-        SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
-        // The host looks at cycle k's state only after cycle k+1 has been enqueued: every kernel is
-        // gated by the device's own convergence word, so a cycle enqueued after convergence is a row
-        // of no-ops that changes nothing, and the stream never drains between cycles.
-        const int slot = cycles & 1;
-        int32_t *err_pin = reinterpret_cast<int32_t *>(c->st_pin + 2);
-        err_pin[slot] = 0;
-        SPK_HIP(hipMemcpyAsync(&c->st_pin[slot], c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
-        if (const int32_t *ew = c->comm->error_word_dev())
-            SPK_HIP(hipMemcpyAsync(&err_pin[slot], ew, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SPK_HIP(hipEventRecord(c->st_ev[slot], s));
         ++cycles;
-        if (stop || o.check_every > 0) {  // the caller asked for prompt host checks: no look-ahead
-            SPK_HIP(hipEventSynchronize(c->st_ev[slot]));
-            st = c->st_pin[slot];
-            c->comm->check(s);
-            if (st.done) break;
-            continue;
-        }
-        if (cycles >= 2) {
-            SPK_HIP(hipEventSynchronize(c->st_ev[slot ^ 1]));
-            st = c->st_pin[slot ^ 1];
-            if (st.done || err_pin[slot ^ 1]) {   // converged one cycle ago (the cycle just enqueued is idle), or a lost peer
-                SPK_HIP(hipStreamSynchronize(s));
-                st = c->st_pin[slot];
-                c->comm->check(s);  // a peer that never arrived: SPK_ERR_COMM instead of a wrong answer
-                --cycles;
-                break;
-            }
-        }
+        SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
+        SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        c->comm->check(s);  // a peer that never arrived: SPK_ERR_COMM instead of a wrong answer
+        if (st.done) break;
     }
     const auto t1 = std::chrono::steady_clock::now();
 
