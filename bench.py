@@ -64,22 +64,37 @@ def spmv_bytes(nrows, nnz):
     return 12 * nnz + 4 * (nrows + 1) + 16 * nrows
 
 
-def iteration_bytes(n, nnz, nnzB, restart, m=4):
-    """Algorithmic bytes of ONE average FGMRES(restart) iteration of the fused
-    Schur path, vec = 8n bytes, j_avg basis vectors,
-    m = planes of B D streamed per pass (spk_get_bd_planes):
-      fused scale+PC : w', dinv, m planes of B D in; v, z, c out    (5 + m) vec
-      SpMV (y += Ax) : 12 nnz + 4 n + x + y in + y out
-      MDot           : V_0..V_j and w                               (j + 2) vec
-      MAXPY + norms  : V_0..V_j, w in/out, m planes of B D          (j + 3 + m) vec
-      per cycle      : x += Z y, true residual (unfused K x, 3 vec) / restart"""
+def solve_bytes(n, nnz, nnzB, restart, steps, planes, m, spmv_matrix_bytes=None):
+    """Algorithmic bytes of ONE spk_fgmres call that executes exactly `steps` iterations of the
+    head-kernel paths, summed over the iterations and restart cycles ACTUALLY
+    executed -- iteration i of the solve has j = i mod restart basis vectors behind it, and a cycle end
+    is paid once per started cycle -- so the figure is right for any --steps, not only for whole cycles.
+    vec = 8 n bytes; planes = planes of B D streamed per pass (spk_get_bd_planes; 0: Jacobi on K = A);
+    m = constraint rows.  Per iteration with j vectors behind it:
+      head (VecScale + PC [+ B^T part])  : w', dinv, planes in; v, z [, c] out   (4 + [1] + planes) vec
+      SpMV  y (+)= A z                   : matrix + 4 n (row pointers) + x + y out [+ y in]
+      MDot                               : V_0..V_j and w                        (j + 2) vec
+      MAXPY + norm [+ B D w']            : V_0..V_j, w in/out, planes            (j + 3 + planes) vec
+    Per started cycle with L iterations: ||r|| [+ B D r] (1 + m) vec, x += Z y (L + 2) vec, true residual
+    (plain K x: matrix + B and B^T entries, b - K x: 5 vec).  Once per solve: ||b|| (1 vec).
+    The matrix term is 12 B per stored non-zero (CSR) unless spmv_matrix_bytes gives the
+    bytes of the layout the kernel really streams."""
     vec = 8 * n
-    j_avg = (restart - 1) / 2.0
-    spmv = spmv_bytes(n, nnz) + vec
-    fused_pc = (5 + m) * vec
-    gs = (j_avg + 2) * vec + (j_avg + 3 + m) * vec
-    cycle = (restart + 2) * vec + (spmv_bytes(n, nnz) + 2 * (12 * nnzB) + 4 * n + vec) + 3 * vec
-    return spmv + fused_pc + gs + cycle / restart
+    mat = 12 * nnz if spmv_matrix_bytes is None else spmv_matrix_bytes
+    saddle = planes > 0
+    total = vec                                              # ||b||
+    done = 0
+    while done < steps:
+        L = min(restart, steps - done)
+        total += (1 + (m if saddle else 0)) * vec            # cycle start
+        for j in range(L):
+            total += (4 + (1 if saddle else 0) + planes) * vec
+            total += mat + 4 * (n + 1) + 2 * vec + (vec if saddle else 0)
+            total += (j + 2) * vec + (j + 3 + planes) * vec
+        total += (L + 2) * vec                               # x += Z y
+        total += mat + 4 * (n + 1) + 2 * vec + 2 * 12 * nnzB + 4 * n + 5 * vec   # true residual of the restart
+        done += L
+    return total
 
 
 def main():
@@ -198,21 +213,27 @@ def main():
             dist.barrier()
 
     kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300, single_reduce=args.single_reduce)
+
+    def timed_solve(steps, **kws):
+        """exactly `steps` iterations between two barriers; MAX over ranks of the wall time"""
+        barrier()
+        t0 = time.perf_counter()
+        inf = ctx.fgmres_device(b_dev, x_dev, max_it=steps, **kws)   # synchronous at return
+        barrier()
+        el = time.perf_counter() - t0
+        assert inf["its"] == steps, inf
+        if dist is not None:
+            import torch
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, inf
+
     # ---- warm-up: W untimed iterations
     if args.warmup > 0:
         ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
     # ---- timed: exactly K iterations
-    barrier()
-    t0 = time.perf_counter()
-    info = ctx.fgmres_device(b_dev, x_dev, max_it=args.steps, **kw)   # synchronous at return
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert info["its"] == args.steps, info
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, info = timed_solve(args.steps, **kw)
 
     # ---- integrity of the timed solve (every N): the residual norm the device carries through its
     # Givens recurrence must equal the TRUE residual ||b - K x|| recomputed from the iterate with one
@@ -232,6 +253,12 @@ def main():
     residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= 1e-6 * max(true_rnorm, 1e-300) or
                        max(true_rnorm, info["rnorm"]) <= 1e-11 * info["rnorm0"])
 
+    # ---- the same solver over WHOLE restart cycles (>= 3), whatever --steps says: a rate that does not
+    # depend on where in a cycle the timed iterations happen to fall (early iterations of a cycle
+    # orthogonalise against few vectors and are cheaper)
+    full_steps = 3 * args.restart
+    elapsed_full, _ = timed_solve(full_steps, **kw)
+
     # ---- the opt-in single-reduction mode on the same K iterations (one all-reduce and three launches
     # per iteration instead of two and four; ||w'||^2 by Pythagoras, see include/spk.h).  Reported
     # beside `value`, never as `value`: PETSc's default Gram-Schmidt makes two reductions.
@@ -239,16 +266,7 @@ def main():
     if args.pc in ("schur-full", "schur-lower", "jacobi") and args.inner_sweeps == 0 and args.single_reduce == 0:
         kws = dict(kw, single_reduce=1)
         ctx.fgmres_device(b_dev, x_dev, max_it=min(args.warmup, 30) or 1, **kws)
-        barrier()
-        t0s = time.perf_counter()
-        infos = ctx.fgmres_device(b_dev, x_dev, max_it=args.steps, **kws)
-        barrier()
-        es = time.perf_counter() - t0s
-        if dist is not None:
-            import torch
-            t = torch.tensor([es], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            es = float(t.item())
+        es, infos = timed_solve(args.steps, **kws)
         single_mode = {"value": args.steps / es, "ms_per_step": es / args.steps * 1e3,
                        "residual_after_steps": infos["rnorm"] / infos["rnorm0"] if infos["rnorm0"] else None,
                        "reductions_per_iteration": 1, "launches_per_iteration": 3}
@@ -270,6 +288,12 @@ def main():
     achieved_layout = spi["layout_bytes"] / (spmv_ms * 1e-3) / 1e9
     # the variant the fused Schur iteration launches: y += A x (y pre-loaded with B^T lambda): 8n more bytes
     acc_ms = ctx.time_kernel("spmv_acc", 0, 20, args.spmv_reps)
+    # per-rank diagnostics of the communicator, gathered to rank 0: an N-GPU line explains itself
+    rank_info = [ctx.comm_info()]
+    if dist is not None and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_info[0])
+        rank_info = gathered
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if os.path.exists(tpath) and world == 1 and M == 1024 and My == 1024 and args.dim == 2:
@@ -286,8 +310,15 @@ def main():
 
     its_per_s = args.steps / elapsed
     nnzB_local = B.nnz if saddle else 0
-    it_bytes = iteration_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, ctx.bd_planes() or B.nrows) \
-        if (saddle and args.inner_sweeps == 0) else None
+    planes = ctx.bd_planes() if saddle else 0
+    # the byte model covers the head-kernel paths: fused Schur (FULL / LOWER) and Jacobi on K = A
+    head_path = args.inner_sweeps == 0 and ((saddle and planes > 0) or (not saddle and sz["n_local"] % 2 == 0))
+    mrows = B.nrows if saddle else 0
+    in_solver_acc = saddle and planes > 0            # the loop launches y += A x (else the plain product)
+    loop_ms = acc_ms if in_solver_acc else spmv_ms
+    loop_alg = alg_bytes + (8 * sz["n_local"] if in_solver_acc else 0)
+    loop_layout = spi["layout_bytes"] + (8 * sz["n_local"] if in_solver_acc else 0)
+    loop_gbps, loop_layout_gbps = loop_alg / (loop_ms * 1e-3) / 1e9, loop_layout / (loop_ms * 1e-3) / 1e9
     out = {
         "metric": METRIC,
         "value": its_per_s,
@@ -316,6 +347,9 @@ def main():
         "spmv_ms": spmv_ms,
         "residual_after_steps": info["rnorm"] / info["rnorm0"] if info["rnorm0"] else None,
         "residual_check": {"recurrence": info["rnorm"], "true": true_rnorm, "consistent": residual_ok},
+        "value_full_cycles": full_steps / elapsed_full,
+        "full_cycles": {"steps": full_steps, "ms_per_step": elapsed_full / full_steps * 1e3,
+                        "note": f"{full_steps // args.restart} whole restart cycles, timed like `value`"},
         "value_with_host_vectors": host_rate,
         "single_reduction_mode": single_mode,
         "setup_seconds": t_setup,
@@ -323,22 +357,41 @@ def main():
         # achieved = ALGORITHMIC (CSR) bytes / time.  When the kernel streams the
         # 2x2-blocked layout its true bytes are fewer: both rates are reported and `frac` is the
         # LOWER of the two fractions, as SURVEY 8(d) prescribes for compressed layouts.
+        # The kernel described is the one the timed loop LAUNCHES for the A block: y += A x on the fused
+        # Schur path (y pre-loaded with B^T lambda: one more vector read), the plain product otherwise.
         "roofline": {"bound": "hbm",
-                     "kernel": ("spmv_bcsr_kernel" if spi["format"] != "csr" else "spmv_stream_kernel") + " (A-block SpMV)",
-                     "format": spi["format"],
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": min(achieved, achieved_layout) / HBM_PEAK_GBS,
-                     "frac_algorithmic_csr_bytes": achieved / HBM_PEAK_GBS,
-                     "achieved_layout_bytes": achieved_layout, "layout_bytes_per_launch": spi["layout_bytes"],
-                     "frac_of_measured_copy": min(achieved, achieved_layout) / HBM_COPY_GBS,
-                     "bytes_per_launch": alg_bytes, "traffic": traffic,
-                     "in_solver_variant": {"kernel": "y += A x (fused Schur path)", "ms": acc_ms,
-                                           "layout_gbps": (spi["layout_bytes"] + 8 * sz["n_local"]) / (acc_ms * 1e-3) / 1e9}},
+                     "kernel": ("spmv_bcsr_kernel" if spi["format"] != "csr" else "spmv_stream_kernel")
+                               + ("<.., ACC=true>: y += A x, as launched by the fused Schur iteration" if in_solver_acc
+                                  else ": y = A x, as launched by the iteration"),
+                     "format": spi["format"], "ms": loop_ms,
+                     "achieved": loop_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": min(loop_gbps, loop_layout_gbps) / HBM_PEAK_GBS,
+                     "frac_algorithmic_csr_bytes": loop_gbps / HBM_PEAK_GBS,
+                     "achieved_layout_bytes": loop_layout_gbps, "layout_bytes_per_launch": loop_layout,
+                     "frac_of_measured_copy": min(loop_gbps, loop_layout_gbps) / HBM_COPY_GBS,
+                     "bytes_per_launch": loop_alg, "traffic": traffic,
+                     "standalone_variant": {"kernel": "y = A x (spk_mult, restarts)", "ms": spmv_ms,
+                                            "csr_gbps": achieved, "layout_gbps": achieved_layout,
+                                            "frac": min(achieved, achieved_layout) / HBM_PEAK_GBS}},
+        "ranks": rank_info,
     }
-    if it_bytes:
-        out["iteration_model"] = {"bytes_per_iteration": it_bytes,
-                                  "achieved_gbps": it_bytes * its_per_s / 1e9,
-                                  "frac_of_peak": it_bytes * its_per_s / 1e9 / HBM_PEAK_GBS}
+    if head_path:
+        # bytes of the solves as executed (j runs over the iterations actually timed; cycle ends counted
+        # as they happened), CSR model and the layout the kernel really streams; the LOWER fraction is claimed
+        mat_layout = spi["layout_bytes"] - 4 * (sz["n_local"] + 1) - 16 * sz["n_local"]
+        models = {}
+        for name, steps_, secs in (("timed_steps", args.steps, elapsed), ("full_cycles", full_steps, elapsed_full)):
+            b_csr = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows)
+            b_lay = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows, mat_layout)
+            models[name] = {"steps": steps_, "bytes_per_iteration_csr_model": b_csr / steps_,
+                            "bytes_per_iteration_layout": b_lay / steps_,
+                            "achieved_gbps_csr_model": b_csr / secs / 1e9, "achieved_gbps_layout": b_lay / secs / 1e9,
+                            "frac_of_peak": min(b_csr, b_lay) / secs / 1e9 / HBM_PEAK_GBS}
+        out["iteration_model"] = models
+    if not residual_ok:
+        # a wrong halo or all-reduce shows here: the number would describe a broken solver
+        out["value"] = None
+        out["error"] = "residual_check failed: the iterate's true residual does not match the recurrence"
 
     # ---- CPU baseline: the oracle (a port of PETSc's algorithm; PETSc itself is not
     # installable here) on a bounded sample of the SAME workload, all host cores.
@@ -358,7 +411,8 @@ def main():
         _, io = O.fgmres(Ao, rhs, B=Bo, pc_type=O.PC_SCHUR if saddle else O.PC_JACOBI, schur_fact=fact,
                          restart=args.restart, max_it=k, rtol=0.0, abstol=0.0, dtol=1e300, threads=cores)
         tc = time.perf_counter() - t0
-        t_spmv = O.time_spmv(Ao, 5, cores) / 5
+        O.time_spmv(Ao, 5, cores)                          # warm-up
+        t_spmv = O.time_spmv(Ao, 60, cores) / 60
         out["cpu_baseline"] = {"value": io["its"] / tc, "unit": "iterations/s", "cores": cores, "kind": "port",
                                "sample": f"{io['its']} FGMRES iterations (first restart cycle) of the same {M}x{My} "
                                          f"system with the oracle, OpenMP over {cores} threads",
@@ -369,6 +423,8 @@ def main():
     ctx.vec_destroy(b_dev); ctx.vec_destroy(x_dev); ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if not residual_ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

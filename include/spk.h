@@ -158,6 +158,33 @@ int spk_comm_init_host(spk_ctx *ctx, int rank, int nranks, const spk_host_comm *
 int spk_comm_enable_peer(spk_ctx *ctx, int32_t *enabled);
 /* "self" | "rccl" | "host-callback" | "local" | "peer-store" */
 const char *spk_comm_backend(const spk_ctx *ctx);
+/* Diagnostics of the communicator, per rank (bench.py gathers them to rank 0 so that an N-GPU run
+ * explains itself): which backend is active and why the peer-store backend stayed off if it did,
+ * which kind of window memory passed the self-test, how many collectives went which way, and how
+ * long the device waited inside them (100 MHz ticks, accumulated by one lane per collective). */
+typedef struct spk_comm_info {
+    int32_t rank, nranks;
+    int32_t peer_enabled;        /* 1: peer-store collectives active */
+    int32_t window_tier;         /* 0 uncached, 1 fine-grained, 2 plain device memory, -1 none */
+    int32_t self_test_ok;        /* all-reduce self-test passed on every rank */
+    int32_t halo_mode;           /* 0 none, 1 granules, 2 bulk chunks, 3 inner backend (fallback) */
+    int32_t halo_fused;          /* 1: the exchange rides inside the head kernels */
+    int32_t device;
+    int64_t n_allreduce_fused;   /* all-reduces executed in the finish of a reducing kernel */
+    int64_t n_allreduce_kernel;  /* as stand-alone granule launches */
+    int64_t n_allreduce_inner;   /* handed to the inner backend (RCCL / host) */
+    int64_t n_halo_fused, n_halo_kernel, n_halo_inner;
+    uint64_t wait_ticks[4];      /* [0] all-reduce after MDot, [1] after MAXPY, [2] stand-alone, [3] halo */
+    uint64_t wait_count[4];
+    char backend[32];
+    char inner_backend[32];
+    char why[256];               /* reason the peer-store backend is off / last set-up message */
+} spk_comm_info;
+int spk_comm_get_info(spk_ctx *ctx, spk_comm_info *info);
+/* Test hook: a `nranks`-rank peer-store all-reduce played by `nranks` workgroups of one launch through
+ * `nranks` windows that all live in this process (no IPC): exercises every lane of the window layout
+ * (up to 8) on one device.  vals: nranks x count inputs; out: nranks x count results (identical rows). */
+int spk_debug_peer_allreduce_loopback(spk_ctx *ctx, int nranks, int count, int rounds, const double *vals, double *out);
 /* In-process logical ranks on one device (parity tests of the partitioned
  * algorithm on a 1-GPU box): a group is shared by `nranks` contexts, each
  * driven by its own host thread. */
@@ -245,6 +272,13 @@ int spk_time_spmv(spk_ctx *ctx, int warmup, int reps, double *ms_per_launch);
  * "pc"); allocates its own scratch vectors. */
 int spk_time_kernel(spk_ctx *ctx, const char *which, int nv, int warmup, int reps,
                     double *ms_per_launch);
+
+/* Test hook: launches a small cross-workgroup reduction in which one partial sum is never
+ * published.  The reducer gives up after timeout_ms and raises the context's sticky execution-error
+ * word; the call (like spk_fgmres / spk_mult when it happens inside them) returns SPK_ERR_HIP -- an
+ * execution failure is never reported as a numerical reason (KSP_DIVERGED_NANORINF).  The context
+ * re-arms its reduction buffer and stays usable. */
+int spk_debug_finish_timeout(spk_ctx *ctx, int timeout_ms);
 
 /* ---- host-only helpers: row-slab partition and halo plan ------------------ */
 /* (callable without a GPU; used by the multi-rank CPU tests) */

@@ -40,7 +40,11 @@ int SpkKSPSetOperators(SpkKSP ksp, const SpkMatCSR *A, const SpkMatCSR *B); /* K
 /* argv-style option list, e.g. {"-ksp_type","fgmres","-ksp_rtol","1e-8",
  * "-pc_type","fieldsplit","-pc_fieldsplit_type","schur",
  * "-pc_fieldsplit_schur_fact_type","full"}.  Unknown -ksp_/-pc_/-fieldsplit_
- * options are an error; other options are ignored (as PETSc leaves them unused). */
+ * options are an error; other options are ignored (as PETSc leaves them unused).
+ * DEVIATION from PETSc, on purpose: -ksp_type and -pc_type have NO default here.  PETSc would fall
+ * back to gmres (left preconditioning) and ilu (bjacobi+ilu in parallel), neither of which this
+ * library implements; SpkKSPSetUp / SpkKSPSolve return SPK_ERR_UNSUPPORTED with a message unless
+ * "-ksp_type fgmres" and "-pc_type jacobi|fieldsplit|none" were given. */
 int SpkKSPSetFromOptions(SpkKSP ksp, int argc, const char *const *argv);    /* KSPSetFromOptions :67 */
 int SpkKSPSetUp(SpkKSP ksp);                                                /* KSPSetUp       :68 */
 /* b, x: host vectors of n_local + m values ([u ; lambda]) */

@@ -659,7 +659,7 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
     const int mk = opt->restart;
     const double haptol = 1e-30;
     int its = 0, reason = 0, hist = 0;
-    double rnorm = 0.0, rnorm0 = 0.0, ttol = 0.0;
+    double rnorm = 0.0, rnorm0 = 0.0, ttol = 0.0, bnorm = 0.0, cnorm0 = 0.0;
 
     spo_set_threads(opt->threads);
 
@@ -678,11 +678,8 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
 #define VV(j) (V + (size_t)N * (j))
 #define ZZ(j) (Z + (size_t)N * (j))
 
-    /* KSPConvergedDefault: ttol = max(rtol*||b||, abstol). */
-    {
-        const double bnorm = spo_vec_norm(N, b);
-        ttol = fmax(opt->rtol * bnorm, opt->abstol);
-    }
+    /* KSPConvergedDefault needs ||b|| when the initial guess is non-zero (see iteration 0 below). */
+    bnorm = spo_vec_norm(N, b);
 
     /* Initial residual into V0. */
     if (!opt->guess_nonzero) {
@@ -698,9 +695,23 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
         /* ---- one restart cycle (KSPFGMRESCycle) ---- */
         int loc = 0, hapend = 0;
         rnorm = spo_vec_norm(N, VV(0));
-        if (its == 0) rnorm0 = rnorm;
+        if (its == 0) {
+            /* KSPConvergedDefault at iteration 0 (PETSc src/ksp/ksp/interface/iterativ.c, as published):
+             * zero initial guess: the reference norm is the initial residual (= ||b||);
+             * -ksp_initial_guess_nonzero: it is ||b||, or the initial residual when b = 0
+             * ("handle special case of zero RHS and nonzero guess").  ttol = max(rtol * that, abstol),
+             * and the divergence test (divtol) compares against the same norm. */
+            double snorm = rnorm;
+            if (opt->guess_nonzero) {
+                snorm = bnorm;
+                if (snorm == 0.0) snorm = rnorm;
+            }
+            rnorm0 = rnorm;   /* reported: residual norm at iteration 0 */
+            cnorm0 = snorm;
+            ttol = fmax(opt->rtol * snorm, opt->abstol);
+        }
         if (history && hist < history_cap && its == 0) history[hist++] = rnorm;
-        reason = spo_converged(rnorm, ttol, opt->abstol, opt->dtol, rnorm0);
+        reason = spo_converged(rnorm, ttol, opt->abstol, opt->dtol, cnorm0);
         if (reason) break;
         spo_scale(N, 1.0 / rnorm, VV(0));
         rs[0] = rnorm;
@@ -766,7 +777,7 @@ int spo_fgmres(const spo_operator *op, const spo_options *opt, const double *b,
             ++loc;
             ++its;
             if (history && hist < history_cap) history[hist++] = rnorm;
-            reason = spo_converged(rnorm, ttol, opt->abstol, opt->dtol, rnorm0);
+            reason = spo_converged(rnorm, ttol, opt->abstol, opt->dtol, cnorm0);
             if (hapend) {
                 if (!reason) reason = SPO_DIVERGED_BREAKDOWN;
                 break;

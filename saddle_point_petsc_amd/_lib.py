@@ -50,6 +50,18 @@ class HostComm(C.Structure):
                 ("allgather", ALLGATHER_CB)]
 
 
+class CommInfo(C.Structure):
+    """spk_comm_info (include/spk.h)."""
+    _fields_ = [
+        ("rank", C.c_int32), ("nranks", C.c_int32), ("peer_enabled", C.c_int32), ("window_tier", C.c_int32),
+        ("self_test_ok", C.c_int32), ("halo_mode", C.c_int32), ("halo_fused", C.c_int32), ("device", C.c_int32),
+        ("n_allreduce_fused", C.c_int64), ("n_allreduce_kernel", C.c_int64), ("n_allreduce_inner", C.c_int64),
+        ("n_halo_fused", C.c_int64), ("n_halo_kernel", C.c_int64), ("n_halo_inner", C.c_int64),
+        ("wait_ticks", C.c_uint64 * 4), ("wait_count", C.c_uint64 * 4),
+        ("backend", C.c_char * 32), ("inner_backend", C.c_char * 32), ("why", C.c_char * 256),
+    ]
+
+
 class MatCSR(C.Structure):
     _fields_ = [
         ("row_begin", C.c_int64), ("nrows_local", C.c_int32), ("pad", C.c_int32),
@@ -81,6 +93,9 @@ def _load():
     L.spk_comm_enable_peer.argtypes = [vp, C.POINTER(i32)]
     L.spk_comm_backend.restype = C.c_char_p
     L.spk_comm_backend.argtypes = [vp]
+    L.spk_comm_get_info.argtypes = [vp, C.POINTER(CommInfo)]
+    L.spk_debug_peer_allreduce_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_int, f64p, f64p]
+    L.spk_debug_finish_timeout.argtypes = [vp, C.c_int]
     L.spk_set_block.argtypes = [vp, C.c_int, i64, i32, i64, i32p, i32p, f64p]
     L.spk_pc_setup.argtypes = [vp, C.c_int, C.c_int]
     L.spk_pc_set_inner.argtypes = [vp, C.c_int, C.c_double]

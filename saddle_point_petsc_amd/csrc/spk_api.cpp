@@ -154,14 +154,92 @@ int spk_comm_enable_peer(spk_ctx *c, int32_t *enabled)
     if (!(off && !strcmp(off, "0")) && c->comm->size() > 1 && strcmp(c->comm->name(), "peer-store") != 0) {
         std::string why;
         spk::Comm *inner = c->comm.release();
-        c->comm.reset(spk::make_peer_comm(inner, c->device, &why));
+        c->comm.reset(spk::make_peer_comm(inner, c->device, &why));  // never throws: returns `inner` when it cannot
         c->err = why;  // informational when the backend stayed off
+        c->peer_why = why;
+    } else if (off && !strcmp(off, "0")) {
+        c->peer_why = "switched off (SPK_COMM_PEER=0)";
     }
     if (enabled) *enabled = strcmp(c->comm->name(), "peer-store") == 0;
     SPK_CATCH(c)
 }
 
 const char *spk_comm_backend(const spk_ctx *c) { return c && c->comm ? c->comm->name() : "self"; }
+
+int spk_comm_get_info(spk_ctx *c, spk_comm_info *o)
+{
+    SPK_TRY(c)
+    if (!o) spk::fail(SPK_ERR_ARG, "spk_comm_get_info: null output");
+    std::memset(o, 0, sizeof *o);
+    o->rank = c->comm->rank();
+    o->nranks = c->comm->size();
+    o->device = c->device;
+    o->window_tier = -1;
+    o->halo_mode = c->peers.empty() ? 0 : 3;
+    std::snprintf(o->backend, sizeof o->backend, "%s", c->comm->name());
+    std::snprintf(o->inner_backend, sizeof o->inner_backend, "%s", c->comm->name());
+    std::snprintf(o->why, sizeof o->why, "%s", c->peer_why.c_str());
+    c->comm->info(o);  // the peer-store backend fills in the rest
+    SPK_CATCH(c)
+}
+
+/* Test hook: a P-rank peer-store all-reduce played by P workgroups of ONE launch through P windows of this
+ * process (no IPC): checks the window layout for every lane up to kPeerMax = 8 on one device.
+ * vals: P x count inputs (row r = rank r's contribution); out: P x count results (every row must hold the
+ * same rank-ordered sums). */
+int spk_debug_peer_allreduce_loopback(spk_ctx *c, int nranks, int count, int rounds, const double *vals, double *out)
+{
+    SPK_TRY(c)
+    if (!vals || !out || nranks < 1 || nranks > spk::k::kPeerMax || count < 1 || count > 64 || rounds < 1)
+        spk::fail(SPK_ERR_ARG, "spk_debug_peer_allreduce_loopback: bad arguments");
+    const size_t wbytes = sizeof(unsigned long long) * (size_t)spk::k::kArSlots * nranks * spk::k::kArGranules;
+    std::vector<unsigned long long *> win((size_t)nranks, nullptr);
+    spk::DevBuf<double> buf;
+    spk::DevBuf<int32_t> err;
+    buf.alloc((size_t)nranks * 64);
+    err.alloc(4);
+    auto cleanup = [&]() { for (auto *w : win) if (w) (void)hipFree(w); };
+    try {
+        for (int r = 0; r < nranks; ++r) {
+            if (hipExtMallocWithFlags((void **)&win[(size_t)r], wbytes, hipDeviceMallocUncached) != hipSuccess) {
+                (void)hipGetLastError();
+                SPK_HIP(hipMalloc((void **)&win[(size_t)r], wbytes));
+            }
+            SPK_HIP(hipMemset(win[(size_t)r], 0, wbytes));
+        }
+        std::vector<double> h((size_t)nranks * 64, 0.0);
+        for (int round = 0; round < rounds; ++round) {   // walks through every slot, and the wrap
+            for (int r = 0; r < nranks; ++r)
+                for (int i = 0; i < count; ++i) h[(size_t)r * 64 + i] = vals[(size_t)r * count + i] * (1.0 + round);
+            SPK_HIP(hipMemcpy(buf.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+            spk::k::PeerAR a{};
+            a.P = nranks;
+            a.seq = (uint32_t)(round + 1);
+            a.timeout_ms = 3000;
+            for (int r = 0; r < nranks; ++r) a.win[r] = win[(size_t)r];
+            a.err = err.p;
+            spk::k::peer_allreduce_loopback(a, buf.p, count, c->stream);
+            SPK_HIP(hipStreamSynchronize(c->stream));
+            int32_t e = 0;
+            SPK_HIP(hipMemcpy(&e, err.p, sizeof e, hipMemcpyDeviceToHost));
+            if (e) spk::fail(SPK_ERR_COMM, "loop-back all-reduce timed out in round %d", round);
+            SPK_HIP(hipMemcpy(h.data(), buf.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int r = 0; r < nranks; ++r)
+                for (int i = 0; i < count; ++i) {
+                    const double v = h[(size_t)r * 64 + i] / (1.0 + round);
+                    if (round == 0) out[(size_t)r * count + i] = v;
+                    else if ((round == 1 && out[(size_t)r * count + i] != v) ||   // x2 is exact: the same bits
+                             std::fabs(out[(size_t)r * count + i] - v) > 1e-13 * std::fabs(v) + 1e-300)
+                        spk::fail(SPK_ERR_COMM, "loop-back all-reduce: round %d differs from round 0", round);
+                }
+        }
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+    SPK_CATCH(c)
+}
 
 int spk_set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
                   const int32_t *rowptr, const int32_t *colidx, const double *val)
@@ -259,6 +337,7 @@ int spk_mult(spk_ctx *c, const double *x, double *y, int mem)
     if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     SPK_HIP(hipStreamSynchronize(c->stream));
     c->comm->check(c->stream);
+    c->check_device_error();
     SPK_CATCH(c)
 }
 
@@ -275,6 +354,7 @@ int spk_pc_apply(spk_ctx *c, const double *x, double *y, int mem)
     if (mem != SPK_MEM_DEVICE) SPK_HIP(hipMemcpyAsync(y, yd, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
     SPK_HIP(hipStreamSynchronize(c->stream));
     c->comm->check(c->stream);
+    c->check_device_error();
     SPK_CATCH(c)
 }
 
@@ -299,6 +379,20 @@ int spk_fgmres(spk_ctx *c, const double *b, double *x, int mem, const spk_opts *
         spk::fgmres(c, rh, xs, o, result, history, history_cap);
         SPK_HIP(hipMemcpy(x, xs, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
     }
+    SPK_CATCH(c)
+}
+
+int spk_debug_finish_timeout(spk_ctx *c, int timeout_ms)
+{
+    SPK_TRY(c)
+    if (timeout_ms < 1 || timeout_ms > 4000) spk::fail(SPK_ERR_ARG, "spk_debug_finish_timeout: 1..4000 ms");
+    c->ensure_scratch();
+    const uint32_t keep = c->fin_ticks;
+    c->fin_ticks = (uint32_t)timeout_ms * 100000u;
+    spk::k::finish_probe(c->fin(c->small.p + 500), c->stream);
+    c->fin_ticks = keep;
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    c->check_device_error();  // throws SPK_ERR_HIP: that is the expected outcome
     SPK_CATCH(c)
 }
 

@@ -114,8 +114,10 @@ RcclApi &rccl()
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     });
-    if (!api.h || !api.CommInitRank || !api.AllReduce || !api.Send || !api.Recv)
-        fail(SPK_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    if (!api.h || !api.CommInitRank || !api.AllReduce || !api.Send || !api.Recv) {
+        const char *de = dlerror();  // one call: the second would return NULL (the message is consumed)
+        fail(SPK_ERR_COMM, "RCCL (librccl.so.1) could not be loaded: %s", de ? de : "missing symbols");
+    }
     return api;
 }
 
@@ -338,7 +340,9 @@ struct WinInfo {
 
 class PeerComm : public Comm {
 public:
-    PeerComm(Comm *inner, int device) : inner_(inner), device_(device), P_(inner->size()), me_(inner->rank())
+    // `inner` is adopted only once construction has succeeded (adopt()): a constructor that throws must
+    // not take the caller's communicator down with it
+    PeerComm(int P, int me, int device) : device_(device), P_(P), me_(me)
     {
         const char *t = getenv("SPK_PEER_TIMEOUT_MS");
         timeout_ms_ = t ? (uint32_t)std::max(1, atoi(t)) : 30000u;
@@ -351,9 +355,11 @@ public:
         const char *hm = getenv("SPK_PEER_HALO_MAX");
         halo_max_ = hm ? std::max(0, atoi(hm)) : 8192;
         err_.alloc(4);
+        stats_.alloc(2 * k::kStatCount);
         std::memset(ar_map_, 0, sizeof ar_map_);
         std::memset(halo_map_, 0, sizeof halo_map_);
     }
+    void adopt(Comm *inner) { inner_.reset(inner); }
     ~PeerComm() override
     {
         close_maps(ar_map_, ar_own_);
@@ -377,10 +383,26 @@ public:
         std::string mywhy;
         bool ok = false;
         for (tier_ = 0; tier_ < 3 && !ok; ++tier_) {
-            ok = alloc_window(&ar_own_, bytes, &mywhy);
-            ok = share_window(ar_own_, ok, 0, nullptr, ar_map_, nullptr, &mywhy) && ok;
+            // every local step is fenced: whatever fails on this rank (an allocation, a HIP call inside the
+            // self-test) must still reach the agree() the other ranks are waiting in
+            try {
+                ok = alloc_window(&ar_own_, bytes, &mywhy);
+            } catch (const Error &e) {
+                ok = false;
+                mywhy = e.msg;
+            }
+            ok = share_window(ar_own_, ok, 0, nullptr, ar_map_, nullptr, &mywhy) && ok;  // collective inside
             ok = agree(ok);
-            if (ok) ok = agree(self_test(&mywhy));
+            if (ok) {
+                bool st = false;
+                try {
+                    st = self_test(&mywhy);
+                } catch (const Error &e) {
+                    mywhy = e.msg;
+                    (void)hipGetLastError();
+                }
+                ok = agree(st);
+            }
             if (!ok) {
                 close_maps(ar_map_, ar_own_);
                 if (ar_own_) (void)hipFree(ar_own_);
@@ -390,7 +412,9 @@ public:
             }
         }
         --tier_;  // the kind that worked (also used for the halo staging)
-        if (!ok && why) *why = mywhy.empty() ? "another rank could not map the windows" : mywhy;
+        if (!ok) why_ = mywhy.empty() ? "another rank could not map the windows or failed its self-test" : mywhy;
+        if (!ok && why) *why = why_;
+        self_test_ok_ = ok;
         return ok;
     }
     // six all-reduces (every slot, and the wrap) of values that differ per rank and per position, on a
@@ -407,6 +431,7 @@ public:
             for (int i = 0; i < 64; ++i) h[(size_t)i] = (double)(me_ + 1) * (i + 1 + round) + 0.25 * round;
             SPK_HIP(hipMemcpy(buf.p, h.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
             k::PeerAR a = next_ar();
+            a.stats = nullptr;  // the self-test is not part of the account
             a.timeout_ms = 5000;
             k::peer_allreduce(a, buf.p, 64, ts);
             SPK_HIP(hipStreamSynchronize(ts));
@@ -431,15 +456,40 @@ public:
     {
         if (count <= 0) return;
         if (2 * count > k::kArGranules) {
+            ++n_ar_inner_;
             inner_->allreduce_sum(dev, count, s);
             return;
         }
-        k::peer_allreduce(next_ar(), dev, count, s);
+        ++n_ar_kernel_;
+        k::peer_allreduce(next_ar(k::kStatArOther), dev, count, s);
     }
-    k::PeerAR fused_allreduce(int count) override
+    k::PeerAR fused_allreduce(int count, int kind) override
     {
         if (!fuse_ || count <= 0 || 2 * count > k::kArGranules) return k::PeerAR{};
-        return next_ar();
+        ++n_ar_fused_;
+        return next_ar(kind);
+    }
+    void info(spk_comm_info *o) override
+    {
+        o->peer_enabled = 1;
+        o->window_tier = tier_;
+        o->self_test_ok = self_test_ok_ ? 1 : 0;
+        o->halo_mode = halo_peers_.empty() && !halo_ok_ ? 0 : (!halo_ok_ ? 3 : (bulk_ ? 2 : 1));
+        o->halo_fused = (halo_ok_ && !bulk_ && fuse_) ? 1 : 0;
+        o->n_allreduce_fused = n_ar_fused_;
+        o->n_allreduce_kernel = n_ar_kernel_;
+        o->n_allreduce_inner = n_ar_inner_;
+        o->n_halo_fused = n_halo_fused_;
+        o->n_halo_kernel = n_halo_kernel_;
+        o->n_halo_inner = n_halo_inner_;
+        unsigned long long st[2 * k::kStatCount] = {0};
+        if (hipMemcpy(st, stats_.p, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+        for (int i = 0; i < 4; ++i) {
+            o->wait_ticks[i] = st[2 * i];
+            o->wait_count[i] = st[2 * i + 1];
+        }
+        std::snprintf(o->inner_backend, sizeof o->inner_backend, "%s", inner_->name());
+        std::snprintf(o->why, sizeof o->why, "%s", why_.c_str());
     }
     void setup_halo(int32_t n_ghost, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                     const std::vector<int64_t> &recv_off) override
@@ -452,12 +502,18 @@ public:
         n_ghost_ = n_ghost;
         std::string why;
         bool ok = peers.size() <= 4;
+        if (!ok) why = "more than four halo neighbours";
         int64_t max_seg = 0;
         for (size_t i = 0; i < peers.size(); ++i)
             max_seg = std::max(max_seg, std::max(send_off[i + 1] - send_off[i], recv_off[i + 1] - recv_off[i]));
         // staging: two parities x n_ghost doubles x two granules (the bulk form needs less: data + flags)
         const size_t bytes = sizeof(unsigned long long) * 4 * (size_t)std::max<int32_t>(n_ghost, 8);
-        ok = alloc_window(&halo_own_, bytes, &why) && ok;
+        try {  // local failures are fenced: the collectives below are reached on every rank
+            ok = alloc_window(&halo_own_, bytes, &why) && ok;
+        } catch (const Error &e) {
+            ok = false;
+            why = e.msg;
+        }
         int64_t roff[k::kPeerMax];
         for (int p = 0; p < k::kPeerMax; ++p) roff[p] = -1;
         for (size_t i = 0; i < peers.size(); ++i)
@@ -491,9 +547,10 @@ public:
             sb.alloc((size_t)std::max<int64_t>(ns, 1));
             rb.alloc((size_t)std::max<int64_t>(nr, 1));
             hipStream_t ts = nullptr;
-            SPK_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
             const uint32_t keep = timeout_ms_;
             timeout_ms_ = 5000;
+            try {
+            SPK_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
             for (int round = 0; round < 2 && ok; ++round) {
                 std::vector<double> hs((size_t)std::max<int64_t>(ns, 1)), hr((size_t)std::max<int64_t>(nr, 1), -1.0);
                 for (size_t i = 0; i < peers.size(); ++i)
@@ -507,23 +564,36 @@ public:
                 for (size_t i = 0; i < peers.size() && ok; ++i)
                     for (int64_t j = recv_off[i]; j < recv_off[i + 1] && ok; ++j)
                         ok = hr[(size_t)j] == (double)peers[i] * 1048576.0 + (double)(j - recv_off[i]) + 0.5 * round;
-                if (error_word()) ok = false;
+                if (error_word()) {
+                    ok = false;
+                    why = "halo self-test timed out";
+                } else if (!ok) {
+                    why = "halo self-test delivered wrong values";
+                }
+            }
+            } catch (const Error &e) {  // a HIP failure inside the self-test: still reach agree()
+                ok = false;
+                why = e.msg;
+                (void)hipGetLastError();
             }
             timeout_ms_ = keep;
-            (void)hipStreamDestroy(ts);
+            if (ts) (void)hipStreamDestroy(ts);
             ok = agree(ok);
-            if (!ok) SPK_HIP(hipMemset(err_.p, 0, sizeof(int32_t)));  // the fallback starts clean
+            if (!ok && hipMemset(err_.p, 0, sizeof(int32_t)) != hipSuccess) (void)hipGetLastError();  // the fallback starts clean
         }
         halo_ok_ = ok;
+        if (!ok && !peers.empty()) why_ = "halo exchange on the inner backend: " + (why.empty() ? std::string("another rank failed") : why);
     }
     void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                   double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override
     {
         if (peers.empty()) return;
         if (!halo_ok_ || peers != halo_peers_ || send_off != halo_send_off_ || recv_off != halo_recv_off_) {
+            ++n_halo_inner_;
             inner_->exchange(sendbuf, peers, send_off, recvbuf, recv_off, s);
             return;
         }
+        ++n_halo_kernel_;
         if (bulk_) {
             k::PeerBulk h{};
             h.npeers = (int)peers.size();
@@ -546,6 +616,7 @@ public:
             h.mdata = reinterpret_cast<const double *>(mine);
             h.mflag = mine + (size_t)n_ghost_;
             h.err = err_.p;
+            h.stats = stats_.p;
             k::peer_exchange_bulk(h, sendbuf, recvbuf, s);
             return;
         }
@@ -563,6 +634,7 @@ public:
         h.recv_off[peers.size()] = recv_off.back();
         h.mine = halo_own_ + 2 * (size_t)par * (size_t)n_ghost_;
         h.err = err_.p;
+        h.stats = stats_.p;
         k::peer_exchange(h, sendbuf, recvbuf, s);
     }
     bool fused_halo(k::SendRanges &sr, double *xghost) override
@@ -581,6 +653,8 @@ public:
         sr.nrecv = n_ghost_;
         sr.xghost = xghost;
         sr.err = err_.p;
+        sr.stats = stats_.p;
+        ++n_halo_fused_;
         return true;
     }
     void check(hipStream_t s) override
@@ -596,9 +670,11 @@ public:
     void set_fuse(bool f) { fuse_ = f; }
 
 private:
-    k::PeerAR next_ar()
+    k::PeerAR next_ar(int kind = k::kStatArOther)
     {
         k::PeerAR a{};
+        a.stats = stats_.p;
+        a.kind = kind;
         a.P = P_;
         a.me = me_;
         a.seq = ++ar_seq_;
@@ -723,6 +799,10 @@ private:
     int tier_ = 0;  // kind of window memory: 0 uncached, 1 fine-grained, 2 plain
     bool fuse_ = true, halo_ok_ = false, bulk_ = false;
     DevBuf<int32_t> err_;
+    DevBuf<unsigned long long> stats_;
+    int64_t n_ar_fused_ = 0, n_ar_kernel_ = 0, n_ar_inner_ = 0, n_halo_fused_ = 0, n_halo_kernel_ = 0, n_halo_inner_ = 0;
+    bool self_test_ok_ = false;
+    std::string why_;
     unsigned long long *ar_own_ = nullptr, *halo_own_ = nullptr;
     unsigned long long *ar_map_[k::kPeerMax], *halo_map_[k::kPeerMax];
     std::vector<void *> opened_;
@@ -740,19 +820,28 @@ Comm *make_peer_comm(Comm *inner, int device, std::string *why)
         if (why) *why = "peer-store backend needs 2.." + std::to_string(k::kPeerMax) + " ranks";
         return inner;
     }
-    auto *pc = new PeerComm(inner, device);
+    // `inner` stays the caller's until the peer communicator is fully up: whatever throws below, the caller
+    // gets `inner` back and keeps a working communicator
+    PeerComm *pc = nullptr;
     bool ok = false;
     try {
+        pc = new PeerComm(inner->size(), inner->rank(), device);
+        pc->adopt(inner);
         ok = pc->enable(why);
     } catch (const Error &e) {
-        // a failure inside the collective set-up cannot be agreed on any more: give the caller the message
+        // (enable() fences its local steps; what arrives here is a failure of the inner communicator itself)
         if (why) *why = e.msg;
+        ok = false;
+    } catch (const std::exception &e) {
+        if (why) *why = e.what();
         ok = false;
     }
     if (!ok) {
-        Comm *back = pc->release_inner();
-        delete pc;
-        return back;
+        if (pc) {
+            (void)pc->release_inner();
+            delete pc;
+        }
+        return inner;
     }
     return pc;
 }

@@ -118,11 +118,19 @@ constexpr int kArSlots = 4;        // all-reduce slots in flight (a rank is neve
 constexpr int kArGranules = 128;   // 8-byte {seq, half} granules per rank and slot = 64 doubles
 // One-shot all-reduce: every rank stores its values as tagged granules into EVERY rank's window
 // (win[p] = rank p's window as mapped here) and sums what arrived in its own, in rank order.
+// Device-side diagnostics of the peer-store backend (spk_comm_get_info): accumulated by ONE lane per
+// collective / waiting workgroup.  stats[2k] = 100 MHz ticks between "my stores are issued" and "every
+// rank's contribution has arrived", stats[2k+1] = number of such waits; k = kStatArDots (all-reduce in
+// the finish of MDot), kStatArNorm (the one after MAXPY), kStatArOther (stand-alone launches),
+// kStatHalo (ghost rows).
+enum { kStatArDots = 0, kStatArNorm = 1, kStatArOther = 2, kStatHalo = 3, kStatCount = 8 };
 struct PeerAR {
     int P, me;                     // P == 0: off
     uint32_t seq, timeout_ms;
     unsigned long long *win[kPeerMax];
     int32_t *err;                  // set to 1 by a poll that timed out
+    unsigned long long *stats;     // nullptr: no accounting
+    int kind;                      // kStatAr*
 };
 // Halo exchange in the same style: my segment for peer i goes to remote[i] (the place in that
 // rank's staging window where it expects my rows), what I expect arrives in `mine`.
@@ -133,6 +141,7 @@ struct PeerHalo {
     const unsigned long long *mine;
     int64_t send_off[5], recv_off[5];
     int32_t *err;
+    unsigned long long *stats;
 };
 // The same exchange for segments that are bandwidth-bound (a node PLANE of a 3-D slab): the payload
 // goes as plain doubles in chunks of kBulkChunk, each followed -- after a system-scope release -- by
@@ -148,6 +157,7 @@ struct PeerBulk {
     int64_t send_off[5], recv_off[5];
     int32_t send_chunk0[5], recv_chunk0[5];  // prefix sums of the chunk counts
     int32_t *err;
+    unsigned long long *stats;
 };
 }  // namespace k
 
@@ -167,7 +177,9 @@ public:
     // all-reduce performed INSIDE the reducing kernel's finish (peer-store backend): returns the
     // window set for the next all-reduce of `count` values, or P == 0 when the backend cannot
     // (the caller then calls allreduce_sum after the kernel)
-    virtual k::PeerAR fused_allreduce(int count) { (void)count; return k::PeerAR{}; }
+    virtual k::PeerAR fused_allreduce(int count, int kind = k::kStatArOther) { (void)count; (void)kind; return k::PeerAR{}; }
+    // what the first multi-GPU run needs to be diagnosable from its own output (spk_comm_get_info)
+    virtual void info(spk_comm_info *out) { (void)out; }
     // halo exchange performed INSIDE the kernel that produces the vector (contiguous send ranges
     // only): fills the peer fields of sr for the next exchange and returns true, or returns false
     // (the caller then calls exchange())
@@ -241,8 +253,10 @@ struct KrylovState {
     // what the kernels of an ITERATION are gated by: set together with `done`, and alone when the
     // rest of the restart cycle is to be skipped (single-reduction mode: a convergence seen by the
     // recurrence is only tentative and is confirmed on the true residual of the restart)
-    int32_t skip_iter, pad_;
+    int32_t skip_iter, guess_nonzero;
     double rnorm, rnorm0, ttol, abstol, dtol, bnorm;
+    double rtol;    // -ksp_rtol: ttol is fixed at iteration 0 (KSPConvergedDefault)
+    double cnorm0;  // the norm the relative and the divergence tests refer to (||b|| or the initial residual)
     double inv_tt;  // 1/||w|| of the last orthogonalised vector (or 1/||r||)
     double tt;
 };
@@ -256,6 +270,9 @@ constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row);
 // arms the block-partials buffer of the cross-workgroup finish (spk_kernels.hip)
 void arm_partials(double *p, size_t n, hipStream_t s);
+// test hook: a reduction with a partial that never arrives (see spk_debug_finish_timeout)
+struct Finish;
+void finish_probe(const Finish &f, hipStream_t s);
 
 // where a reducing kernel leaves its result: block partials (armed with the sentinel of the
 // "last block reduces" protocol, spk_kernels.hip) and the output slot
@@ -263,6 +280,10 @@ struct Finish {
     double *partials;
     double *out;
     PeerAR ar;  // P != 0 (mdot, maxpy only): the finishing workgroup also sums over the ranks
+    // sticky execution-error word of the context (bit 0: a partial never arrived within fin_ticks);
+    // fgmres / the API calls turn it into SPK_ERR_HIP and re-arm the partials
+    int32_t *err = nullptr;
+    uint32_t fin_ticks = 400000000u;  // bound of the reducer's wait, 100 MHz ticks (4 s)
 };
 
 // off-rank part folded into the SpMV epilogue (rowptr over ALL local rows; nullptr: none)
@@ -286,6 +307,7 @@ struct SendRanges {
     int32_t nrecv;
     double *xghost;
     int32_t *err;
+    unsigned long long *stats;
 };
 
 // y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
@@ -339,6 +361,7 @@ void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done
 void gather(const double *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s);
 // peer-store collectives (stand-alone launches; the fused forms live in the reducing kernels)
 void peer_allreduce(const PeerAR &a, double *buf, int count, hipStream_t s);
+void peer_allreduce_loopback(const PeerAR &a, double *buf, int count, hipStream_t s);  // test hook: workgroup r = rank r
 void peer_exchange(const PeerHalo &h, const double *sendbuf, double *recvbuf, hipStream_t s);
 void peer_exchange_bulk(const PeerBulk &h, const double *sendbuf, double *recvbuf, hipStream_t s);
 // Jacobi / Schur pieces
@@ -406,6 +429,7 @@ struct spk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     mutable std::string err;
+    std::string peer_why;  // why the peer-store backend is off (spk_comm_get_info)
     std::unique_ptr<spk::Comm> comm;
 
     // sizes
@@ -448,8 +472,13 @@ struct spk_ctx {
     // scratch
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd
     spk::DevBuf<double> small;     // reduced scalars (256 doubles)
-    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, out, spk::k::PeerAR{}}; }
-    spk::k::Finish fin(double *out, const spk::k::PeerAR &ar) { return spk::k::Finish{partials.p, out, ar}; }
+    spk::DevBuf<int32_t> errw;     // sticky device-side execution-error word (Finish::err)
+    uint32_t fin_ticks = 400000000u;
+    spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, out, spk::k::PeerAR{}, errw.p, fin_ticks}; }
+    spk::k::Finish fin(double *out, const spk::k::PeerAR &ar) { return spk::k::Finish{partials.p, out, ar, errw.p, fin_ticks}; }
+    // throws SPK_ERR_HIP when a device-side wait of a cross-workgroup reduction has timed out (call after a
+    // sync); re-arms the partials so that the context stays usable
+    void check_device_error();
     spk::DevBuf<double> y1tmp, ttmp;
 
     // Krylov workspace (sized by restart)

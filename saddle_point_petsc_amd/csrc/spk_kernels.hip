@@ -119,7 +119,13 @@ __device__ __forceinline__ bool arrive_last(unsigned nblocks)
 // when everything has arrived), then a fixed binary tree; the result is valid in LDS scratch[0..k)
 // after return.  scratch: T doubles.
 constexpr int kFinBatch = 16;  // partials a reducer thread requests together (registers of the WHOLE kernel: 32 cost 2x the VGPRs)
-__device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, int k, double *scratch)
+// where a reducer reports a partial that never arrived (execution failure, not a numerical one): the
+// context's sticky error word; the bound of the wait in 100 MHz ticks
+struct FinErr {
+    int32_t *err;
+    uint32_t ticks;
+};
+__device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, int k, double *scratch, FinErr fe)
 {
     const int T = blockDim.x;
     int kk = 1;
@@ -144,7 +150,11 @@ __device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, i
 #pragma unroll
                 for (int u = 0; u < kFinBatch; ++u) armed_seen = armed_seen || is_sentinel(v[u]);
                 if (armed_seen) __builtin_amdgcn_s_sleep(1);
-            } while (armed_seen && wall_clock64() - t0 < 400000000ull);  // 4 s at 100 MHz
+            } while (armed_seen && wall_clock64() - t0 < (unsigned long long)fe.ticks);  // default 4 s at 100 MHz
+            // a slot still armed after the bound: its workgroup never published (never dispatched, or the
+            // launch was rejected half way).  Not a numerical event: raise the context's sticky error word --
+            // the host turns it into SPK_ERR_HIP and re-arms the whole buffer before the next use
+            if (armed_seen && fe.err) __hip_atomic_store(fe.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < kFinBatch; ++u) {
                 const int b = b0 + u * nsl;
@@ -170,6 +180,24 @@ __global__ void arm_partials_kernel(double *p, size_t n)
 void arm_partials(double *p, size_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(arm_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+
+// Test hook (spk_debug_finish_timeout): a four-workgroup reduction whose last partial is never
+// published -- the reducer must give up after fe.ticks, raise the error word and leave the kernel.
+__global__ __launch_bounds__(256) void finish_probe_kernel(double *partials, double *out, FinErr fe)
+{
+    __shared__ double scratch[256];
+    if (blockIdx.x + 1 < gridDim.x) {
+        if (threadIdx.x == 0) publish(partials + (size_t)blockIdx.x * kPartialLd, 1.0);
+        return;
+    }
+    __syncthreads();
+    final_reduce(partials, gridDim.x, kPartialLd, 1, scratch, fe);  // slot gridDim.x - 1 stays armed
+    if (threadIdx.x == 0) out[0] = scratch[0];
+}
+void finish_probe(const Finish &f, hipStream_t s)
+{
+    hipLaunchKernelGGL(finish_probe_kernel, dim3(4), dim3(256), 0, s, f.partials, f.out, FinErr{f.err, f.fin_ticks});
 }
 
 // ---------------------------------------------------------------------------
@@ -238,6 +266,7 @@ __device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const doub
     const size_t mine = ((size_t)slot * a.P + a.me) * kArGranules + t;
     for (int p = 0; p < a.P; ++p) st_sys(a.win[p] + mine, g);
     const unsigned long long *own = a.win[a.me] + (size_t)slot * a.P * kArGranules + t;
+    const unsigned long long tw0 = (a.stats && t == 0) ? wall_clock64() : 0ull;
     double sum = 0.0;
     bool ok = true;
     for (int p = 0; p < a.P; ++p) {
@@ -245,6 +274,10 @@ __device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const doub
         ok = granule_wait(own + (size_t)p * kArGranules, a.seq, a.timeout_ms, lo, a.err) && ok;
         const uint32_t other = __shfl_xor(lo, 1, kWave);
         sum += join_halves(lo, other);  // meaningful in even lanes
+    }
+    if (a.stats && t == 0) {  // one lane accounts for the collective: stores issued -> every rank's lane arrived
+        atomicAdd(a.stats + 2 * a.kind, wall_clock64() - tw0);
+        atomicAdd(a.stats + 2 * a.kind + 1, 1ull);
     }
     if (!(t & 1)) out[t >> 1] = sum;
     if (!ok) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -519,7 +552,7 @@ __global__ __launch_bounds__(kVT) void wide_dot_kernel(
     const int32_t *__restrict__ colidx, const double *__restrict__ val,
     const int32_t *__restrict__ winptr, int m, int nwin, const double *__restrict__ x,
     const double *__restrict__ scale, double *__restrict__ partials,
-    double *__restrict__ out, const int32_t *__restrict__ done)
+    double *__restrict__ out, FinErr fe, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     __shared__ double scratch[kVT];
@@ -553,7 +586,7 @@ __global__ __launch_bounds__(kVT) void wide_dot_kernel(
         __syncthreads();
     }
     if (!arrive_last(gridDim.x)) return;
-    final_reduce(partials, nwin, kPartialLd, m, scratch);
+    final_reduce(partials, nwin, kPartialLd, m, scratch, fe);
     if ((int)threadIdx.x < m) out[threadIdx.x] = scratch[threadIdx.x];
 }
 
@@ -562,7 +595,7 @@ static void wide_dot_scaled(const WideDev &B, const double *x, const double *sca
 {
     if (B.nwin == 0) return;
     hipLaunchKernelGGL(wide_dot_kernel, dim3(B.nwin), dim3(kVT), 0, s, B.colidx.p, B.val.p,
-                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.out, done);
+                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
 }
 void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s)
 {
@@ -593,7 +626,7 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
                                                  const double *__restrict__ w, int64_t n2,
                                                  int64_t n_dot, double *__restrict__ partials,
                                                  int with_ww,
-                                                 double *__restrict__ out, PeerAR ar, int split,
+                                                 double *__restrict__ out, PeerAR ar, int split, FinErr fe,
                                                  const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -677,7 +710,7 @@ __global__ __launch_bounds__(T) void mdot_kernel(const double *__restrict__ V, i
     }
     if (!arrive_last(gridDim.x)) return;
     const int k = nv + (with_ww ? 1 : 0);
-    final_reduce(partials, gridDim.x, kPartialLd, k, lds);
+    final_reduce(partials, gridDim.x, kPartialLd, k, lds, fe);
     // across ranks: the workgroup that finished this rank's sums also exchanges them (no launch of its own)
     if (ar.P) peer_allreduce_block(ar, lds, k, out);
     else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
@@ -703,7 +736,7 @@ __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__
                                                       const double *__restrict__ V2, int nv1,
                                                       const double *__restrict__ w, int64_t n2, int64_t n_dot,
                                                       double *__restrict__ partials, int with_ww, double *__restrict__ out,
-                                                      PeerAR ar, int split, const int32_t *__restrict__ done)
+                                                      PeerAR ar, int split, FinErr fe, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     __shared__ double lds[256];
@@ -783,7 +816,7 @@ __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__
     }
     if (!arrive_last(gridDim.x)) return;
     const int k = nv + (with_ww ? 1 : 0);
-    final_reduce(partials, gridDim.x, kPartialLd, k, lds);
+    final_reduce(partials, gridDim.x, kPartialLd, k, lds, fe);
     if (ar.P) peer_allreduce_block(ar, lds, k, out);
     else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
 }
@@ -841,10 +874,10 @@ static int vec_grid(int64_t n2, int T = kVT)
 template <int T, int U, int G>
 static void mdot_launch(int ng, int grid, hipStream_t s, const double *Vp, int64_t ldv, int cnt, const double *V2, int nv1,
                         const double *w, int64_t n2, int64_t n_dot, double *pp, int last, double *oo,
-                        const PeerAR &ar, int split, const int32_t *done)
+                        const PeerAR &ar, int split, FinErr fe, const int32_t *done)
 {
 #define SPK_MDOT(NGG) hipLaunchKernelGGL((mdot_kernel<NGG, T, G, true, U>), dim3(grid), dim3(T), 0, s, Vp, ldv, cnt, V2, nv1, w, \
-                                         n2, n_dot, pp, last, oo, ar, split, done)
+                                         n2, n_dot, pp, last, oo, ar, split, fe, done)
     switch (ng) {
     case 1: SPK_MDOT(1); break;
     case 2: SPK_MDOT(2); break;
@@ -881,7 +914,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         const WsShape ws = ws_shape(n2);
         if (ws.on) {
 #define SPK_MDOT_WS(VW, UU, GG) hipLaunchKernelGGL((mdot_ws_kernel<VW, UU, GG, true>), dim3(ws.grid), dim3(256), 0, s, Vp, ldv, cnt, \
-                                                   V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, done)
+                                                   V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, FinErr{f.err, f.fin_ticks}, done)
 #define SPK_MDOT_WS_U(VW) do { if (ws.U == 8) SPK_MDOT_WS(VW, 8, 2); else if (ws.U == 4) SPK_MDOT_WS(VW, 4, 4); else SPK_MDOT_WS(VW, 2, 4); } while (0)
             const int per = (cnt + 3) / 4;
             if (per <= 4) SPK_MDOT_WS_U(4);
@@ -892,7 +925,7 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
             v0 += 40;
             continue;
         }
-#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, done
+#define SPK_MDOT_ARGS ng, vs.grid, s, Vp, ldv, cnt, V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, FinErr{f.err, f.fin_ticks}, done
         if (vs.T == 512) mdot_launch<512, 4, 4>(SPK_MDOT_ARGS);
         else if (vs.U == 4) mdot_launch<256, 4, 4>(SPK_MDOT_ARGS);
         else if (vs.U == 2 && vs.G == 8) mdot_launch<256, 2, 8>(SPK_MDOT_ARGS);
@@ -918,7 +951,7 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
                                                          double *__restrict__ out,
                                                          const double *__restrict__ bd, int64_t ldb,
                                                          int64_t n_bd, int m, double *__restrict__ w1side,
-                                                         PythArgs py, PeerAR ar, int packed,
+                                                         PythArgs py, PeerAR ar, int packed, FinErr fe,
                                                          const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -1065,7 +1098,7 @@ __global__ __launch_bounds__(T) void maxpy_kernel(const double *__restrict__ V, 
     }
     if (!arrive_last(gridDim.x)) return;
     const int k = 1 + (MP > 0 ? m : 0);
-    final_reduce(partials, gridDim.x, kPartialLd, k, red);
+    final_reduce(partials, gridDim.x, kPartialLd, k, red, fe);
     if (ar.P) peer_allreduce_block(ar, red, k, out);
     else if ((int)threadIdx.x < k) out[threadIdx.x] = red[threadIdx.x];
 }
@@ -1077,7 +1110,8 @@ static void maxpy_launch(int mp, int grid, hipStream_t s, const double *V, int64
                          int packed, const int32_t *done)
 {
 #define SPK_MAXPY(MPP) hipLaunchKernelGGL((maxpy_kernel<T, G, true, MPP, U>), dim3(grid), dim3(T), 0, s, V, ldv, nv, nv_dev, a, \
-                                          sign, w, n2, n_dot, f.partials, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, packed, done)
+                                          sign, w, n2, n_dot, f.partials, f.out, bd, ldb, n_bd, m, w1side, py, f.ar, packed, \
+                                          FinErr{f.err, f.fin_ticks}, done)
     if (mp == 4) SPK_MAXPY(4);
     else if (mp == 8) SPK_MAXPY(8);
     else SPK_MAXPY(0);
@@ -1157,7 +1191,7 @@ void axpby(double a, const double *x, double b, double *y, int64_t n, const int3
 
 __global__ __launch_bounds__(kVT) void sqnorm_kernel(const double *__restrict__ x, int64_t n2,
                                                           int64_t n_dot, double *__restrict__ partials,
-                                                          double *__restrict__ out,
+                                                          double *__restrict__ out, FinErr fe,
                                                           const int32_t *__restrict__ done)
 {
     if (done && *done) return;
@@ -1178,14 +1212,14 @@ __global__ __launch_bounds__(kVT) void sqnorm_kernel(const double *__restrict__ 
         publish(partials + (size_t)blockIdx.x * kPartialLd, t);
     }
     if (!arrive_last(gridDim.x)) return;
-    final_reduce(partials, gridDim.x, kPartialLd, 1, red);
+    final_reduce(partials, gridDim.x, kPartialLd, 1, red, fe);
     if (threadIdx.x == 0) out[0] = red[0];
 }
 void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n_dot + 1) / 2;
     const int grid = vec_grid(n2);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.out, done);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
 }
 
 __global__ __launch_bounds__(kThreads) void gather_kernel(const double *__restrict__ x,
@@ -1216,6 +1250,20 @@ void peer_allreduce(const PeerAR &a, double *buf, int count, hipStream_t s)
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(128), 0, s, a, buf, count);
 }
 
+// Loop-back form for tests: workgroup r plays rank r of a P-rank all-reduce through P windows that all live
+// in this process (spk_debug_peer_allreduce_loopback): every lane of the window layout is exercised on one
+// device, including lanes 4..7 that a box with at most six GPU processes cannot reach otherwise.
+__global__ __launch_bounds__(2 * 64) void peer_allreduce_loopback_kernel(PeerAR a, double *buf, int count)
+{
+    a.me = (int)blockIdx.x;
+    peer_allreduce_block(a, buf + (size_t)a.me * 64, count, buf + (size_t)a.me * 64);
+}
+void peer_allreduce_loopback(const PeerAR &a, double *buf, int count, hipStream_t s)
+{
+    if (count < 1 || 2 * count > kArGranules || a.P < 1 || a.P > kPeerMax) fail(SPK_ERR_ARG, "loop-back all-reduce: bad shape");
+    hipLaunchKernelGGL(peer_allreduce_loopback_kernel, dim3(a.P), dim3(128), 0, s, a, buf, count);
+}
+
 // one thread per granule: send first, then wait for the granule with the same index of my own staging
 __global__ __launch_bounds__(kThreads) void peer_exchange_kernel(PeerHalo h, const double *__restrict__ sendbuf,
                                                                  double *__restrict__ recvbuf)
@@ -1231,7 +1279,12 @@ __global__ __launch_bounds__(kThreads) void peer_exchange_kernel(PeerHalo h, con
     }
     if (g < nr2) {
         uint32_t lo;
+        const unsigned long long tw0 = (h.stats && threadIdx.x == 0) ? wall_clock64() : 0ull;
         const bool ok = granule_wait(h.mine + g, h.seq, h.timeout_ms, lo, h.err);
+        if (h.stats && threadIdx.x == 0) {
+            atomicAdd(h.stats + 2 * kStatHalo, wall_clock64() - tw0);
+            atomicAdd(h.stats + 2 * kStatHalo + 1, 1ull);
+        }
         const uint32_t other = __shfl_xor(lo, 1, kWave);
         if (!(g & 1)) recvbuf[g >> 1] = join_halves(lo, other);
         if (!ok) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1276,6 +1329,7 @@ __global__ __launch_bounds__(kThreads) void peer_exchange_bulk_kernel(PeerBulk h
     const int64_t n = rem < kBulkChunk ? rem : kBulkChunk;
     if (threadIdx.x == 0) {
         bool ok = true;
+        const unsigned long long tw0 = h.stats ? wall_clock64() : 0ull;
         if (ld_sys(h.mflag + e0) != (unsigned long long)h.seq) {
             const unsigned long long t0 = wall_clock64();
             for (;;) {
@@ -1287,6 +1341,10 @@ __global__ __launch_bounds__(kThreads) void peer_exchange_bulk_kernel(PeerBulk h
                     break;
                 }
             }
+        }
+        if (h.stats) {
+            atomicAdd(h.stats + 2 * kStatHalo, wall_clock64() - tw0);
+            atomicAdd(h.stats + 2 * kStatHalo + 1, 1ull);
         }
         if (!ok) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         okf = ok;
@@ -1629,7 +1687,7 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
                                                         const double *__restrict__ bd, int64_t ldb, int64_t n_bd,
                                                         int m, double *__restrict__ w1side,
                                                         double *__restrict__ partials, double *__restrict__ out,
-                                                        const int32_t *__restrict__ done)
+                                                        FinErr fe, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
     constexpr int T = 512, NR = MP + 1, W = T / kWave;
@@ -1669,7 +1727,7 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
         if ((int)threadIdx.x <= m) publish(partials + (size_t)blockIdx.x * kPartialLd + threadIdx.x, t);
     }
     if (!arrive_last(gridDim.x)) return;
-    final_reduce(partials, gridDim.x, kPartialLd, 1 + m, red);
+    final_reduce(partials, gridDim.x, kPartialLd, 1 + m, red, fe);
     if ((int)threadIdx.x < 1 + m) out[threadIdx.x] = red[threadIdx.x];
 }
 void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
@@ -1678,9 +1736,9 @@ void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int6
     const int64_t n2 = (n + 1) / 2;
     const int grid = vec_grid(n2, 512);
     if (m <= 4)
-        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
     else
-        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
 }
 
 __global__ void sum_slots_kernel(const double *__restrict__ slots, int nslots, int ld, int count,
@@ -1707,7 +1765,7 @@ __device__ __forceinline__ int converged_default(double rnorm, const KrylovState
 {
     if (isnan(rnorm) || isinf(rnorm)) return SPK_DIVERGED_NANORINF;
     if (rnorm <= st->ttol) return (rnorm < st->abstol) ? SPK_CONVERGED_ATOL : SPK_CONVERGED_RTOL;
-    if (rnorm >= st->dtol * st->rnorm0) return SPK_DIVERGED_DTOL;
+    if (rnorm >= st->dtol * st->cnorm0) return SPK_DIVERGED_DTOL;
     return 0;
 }
 
@@ -1727,7 +1785,10 @@ __global__ void krylov_init_kernel(KrylovArrays ka, spk_opts o, const double *bn
     st->bnorm = sqrt(*bnorm2);
     st->abstol = o.abstol;
     st->dtol = o.dtol;
-    st->ttol = fmax(o.rtol * st->bnorm, o.abstol);
+    st->rtol = o.rtol;
+    st->guess_nonzero = o.guess_nonzero;
+    st->ttol = fmax(o.rtol * st->bnorm, o.abstol);  // fixed at iteration 0 (krylov_cycle_begin)
+    st->cnorm0 = st->bnorm;
     st->rnorm = 0.0;
     st->rnorm0 = 0.0;
     st->inv_tt = 1.0;
@@ -1748,7 +1809,17 @@ __global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, d
     const double rnorm = sqrt(*nrm2);
     st->rnorm = rnorm;
     if (st->its == 0) {
+        // KSPConvergedDefault at iteration 0 (PETSc iterativ.c, as published): zero initial guess -> the
+        // reference norm is the initial residual; -ksp_initial_guess_nonzero -> ||b||, or the initial
+        // residual when b = 0.  ttol and the divergence test both refer to it.
+        double snorm = rnorm;
+        if (st->guess_nonzero) {
+            snorm = st->bnorm;
+            if (snorm == 0.0) snorm = rnorm;
+        }
         st->rnorm0 = rnorm;
+        st->cnorm0 = snorm;
+        st->ttol = fmax(st->rtol * snorm, st->abstol);
         if (ka.hist_cap > 0) ka.hist[0] = rnorm;
     }
     int reason = converged_default(rnorm, st);
@@ -1939,7 +2010,12 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
         const int64_t g = (int64_t)(bid - gmain) * kThreads + threadIdx.x;
         if (g < 2 * (int64_t)sr.nrecv) {
             uint32_t lo;
+            const unsigned long long tw0 = (sr.stats && threadIdx.x == 0) ? wall_clock64() : 0ull;
             const bool ok = granule_wait(sr.mine + g, sr.seq, sr.timeout_ms, lo, sr.err, done);
+            if (sr.stats && threadIdx.x == 0) {  // one lane per waiting workgroup
+                atomicAdd(sr.stats + 2 * kStatHalo, wall_clock64() - tw0);
+                atomicAdd(sr.stats + 2 * kStatHalo + 1, 1ull);
+            }
             const uint32_t other = __shfl_xor(lo, 1, kWave);
             if (!(g & 1)) sr.xghost[g >> 1] = join_halves(lo, other);
             if (!ok) __hip_atomic_store(sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2128,7 +2204,12 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
         const int64_t g = (int64_t)(bid - gmain) * T + threadIdx.x;
         if (g < 2 * (int64_t)sr.nrecv) {
             uint32_t lo;
+            const unsigned long long tw0 = (sr.stats && threadIdx.x == 0) ? wall_clock64() : 0ull;
             const bool ok = granule_wait(sr.mine + g, sr.seq, sr.timeout_ms, lo, sr.err, done);
+            if (sr.stats && threadIdx.x == 0) {  // one lane per waiting workgroup
+                atomicAdd(sr.stats + 2 * kStatHalo, wall_clock64() - tw0);
+                atomicAdd(sr.stats + 2 * kStatHalo + 1, 1ull);
+            }
             const uint32_t other = __shfl_xor(lo, 1, kWave);
             if (!(g & 1)) sr.xghost[g >> 1] = join_halves(lo, other);
             if (!ok) __hip_atomic_store(sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

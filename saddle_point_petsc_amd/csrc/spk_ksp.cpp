@@ -18,6 +18,9 @@ struct SpkKSP_s {
     double inner_omega = 1.0;  // -fieldsplit_0_ksp_richardson_scale
     bool inner_richardson = false;
     bool have_ops = false, is_setup = false, has_B = false;
+    // PETSc's own defaults (-ksp_type gmres with left preconditioning, -pc_type ilu / bjacobi+ilu) are
+    // not implemented here: a run that leaves them unset must be refused, not silently changed
+    bool ksp_type_given = false, pc_type_given = false;
     bool monitor = false, print_reason = false, view = false;
     spk_result result;
     std::vector<double> history;
@@ -152,6 +155,7 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
         if (key == "-ksp_type") {
             if (!val) return need("a type");
             if (std::string(val) != "fgmres") return bad();
+            k->ksp_type_given = true;
         } else if (key == "-ksp_rtol") {
             if (!val || !parse_double(val, &k->opts.rtol)) return need("a real");
         } else if (key == "-ksp_atol") {
@@ -195,6 +199,7 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
             else if (v == "jacobi") k->pc_type = SPK_PC_JACOBI;
             else if (v == "fieldsplit") k->pc_type = SPK_PC_SCHUR;
             else return bad();
+            k->pc_type_given = true;
         } else if (key == "-pc_fieldsplit_type") {
             if (!val) return need("a type");
             if (std::string(val) != "schur") return bad();
@@ -243,6 +248,12 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
 int SpkKSPSetUp(SpkKSP k)
 {
     if (!k) return SPK_ERR_ARG;
+    if (!k->ksp_type_given)
+        return set_err(k, SPK_ERR_UNSUPPORTED, "KSPSetUp: no -ksp_type given; PETSc's default (gmres, left preconditioning) is "
+                                               "not implemented -- pass -ksp_type fgmres");
+    if (!k->pc_type_given)
+        return set_err(k, SPK_ERR_UNSUPPORTED, "KSPSetUp: no -pc_type given; PETSc's default (ilu, bjacobi+ilu in parallel) is "
+                                               "not implemented -- pass -pc_type jacobi | fieldsplit | none");
     if (!k->have_ops) return set_err(k, SPK_ERR_STATE, "KSPSetUp: KSPSetOperators has not been called");
     if (k->pc_type == SPK_PC_SCHUR && !k->has_B)
         return set_err(k, SPK_ERR_STATE, "KSPSetUp: -pc_type fieldsplit (schur) needs the constraint block B");

@@ -30,9 +30,26 @@ void spk_ctx::ensure_scratch()
         k::arm_partials(partials.p, partials.n, stream);
         SPK_HIP(hipStreamSynchronize(stream));
     }
+    if (!errw.p) errw.alloc(4);
     if (!small.p) small.alloc(512);
     if (!y1tmp.p) y1tmp.alloc(64);
     if (!ttmp.p) ttmp.alloc(64);
+}
+
+void spk_ctx::check_device_error()
+{
+    if (!errw.p) return;
+    int32_t e = 0;
+    SPK_HIP(hipMemcpy(&e, errw.p, sizeof e, hipMemcpyDeviceToHost));
+    if (!e) return;
+    // the word is sticky on the device; clear it and put every slot of the partials buffer back to the
+    // sentinel (a workgroup that publishes late would otherwise leave a stale "arrived" slot behind)
+    SPK_HIP(hipStreamSynchronize(stream));
+    SPK_HIP(hipMemset(errw.p, 0, sizeof(int32_t)));
+    k::arm_partials(partials.p, partials.n, stream);
+    SPK_HIP(hipStreamSynchronize(stream));
+    fail(SPK_ERR_HIP, "a cross-workgroup reduction timed out on the device (a workgroup never published its partial "
+                      "sums within %.1f s): execution failure, the result of this call is not valid", fin_ticks / 1e8);
 }
 
 void spk_ctx::ensure_vectors()
@@ -77,9 +94,30 @@ static void upload_csr(CsrDev &D, int32_t nrows, int32_t ncols, const VR &rowptr
     }
 }
 
+// Collective agreement on a set-up step (KSPSetOperators is collective, as in PETSc): every rank
+// reports whether its LOCAL part succeeded; when any rank failed, ALL ranks throw -- the failing one its
+// own message, the others a note naming it -- so nobody is left waiting inside the next collective.
+static void agree_or_fail(spk_ctx *c, const Error *mine, const char *step)
+{
+    const int P = c->comm->size();
+    if (P > 1) {
+        std::vector<int32_t> all((size_t)P, 0);
+        const int32_t ok = mine ? 0 : 1;
+        c->comm->host_allgather(&ok, all.data(), sizeof ok);
+        if (!mine)
+            for (int r = 0; r < P; ++r)
+                if (!all[(size_t)r])
+                    fail(SPK_ERR_COMM, "%s: rank %d failed its local part; the collective set-up is abandoned on every rank", step, r);
+    }
+    if (mine) throw *mine;
+}
+
 static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
                         const int32_t *rowptr, const int32_t *colidx, const double *val)
 {
+    SplitCsr sp;
+    Error local{0, ""};
+    try {  // ---- local part: validation, split, uploads (no collective inside)
     if (rowptr[0] != 0) fail(SPK_ERR_ARG, "A00: rowptr[0] must be 0");
     if (row_begin < 0 || row_begin + nrows_local > ncols_global)
         fail(SPK_ERR_ARG, "A00: rows [%lld,%lld) outside the %lld x %lld block", (long long)row_begin,
@@ -87,7 +125,6 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     for (int32_t r = 0; r < nrows_local; ++r)
         if (rowptr[r + 1] < rowptr[r]) fail(SPK_ERR_ARG, "A00: rowptr not monotone at row %d", r);
 
-    SplitCsr sp;
     split_csr(row_begin, nrows_local, rowptr, colidx, val, sp, ncols_global);  // threaded, validates the columns
     if (sp.bad_column) fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", sp.bad_value, (long long)ncols_global);
     c->n_global = ncols_global;
@@ -166,6 +203,13 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
         }
     upload_csr(c->Ao, (int32_t)rows.size(), c->n_ghost, orp, sp.o_colidx, sp.o_val, false);
     c->ao_rows.upload(rows.data(), rows.size(), 8);
+    } catch (const Error &e) {
+        local = e;
+    } catch (const std::exception &e) {
+        local = Error{SPK_ERR_NOMEM, e.what()};
+    }
+    c->have_A = false;
+    agree_or_fail(c, local.code ? &local : nullptr, "A00");
 
     // ---- halo plan (VecScatter of MatMult_MPIAIJ) ----
     const int P = c->comm->size(), me = c->comm->rank();
@@ -200,10 +244,12 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
             c->send_off.push_back(c->send_off.back() + nsend);
             c->recv_off.push_back(c->recv_off.back() + nrecv);
         }
-        if (c->recv_off.back() != c->n_ghost) fail(SPK_ERR_ARG, "A00: ghost columns not owned by any rank");
     } else if (c->n_ghost != 0) {
         fail(SPK_ERR_ARG, "A00: %d columns fall outside the local rows but there is only one rank", c->n_ghost);
     }
+    local = Error{0, ""};
+    try {  // ---- local again: the rest of the plan and its uploads; agreed on before the collective setup_halo
+    if (P > 1 && c->recv_off.back() != c->n_ghost) fail(SPK_ERR_ARG, "A00: ghost columns not owned by any rank");
     c->send_idx.upload(send_idx.data(), send_idx.size(), 8);
     c->send_buf.alloc(send_idx.size(), 8);
     // off-rank part in "SpMV epilogue" form: row pointers over all local rows
@@ -228,6 +274,12 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
         }
     }
     c->xghost.alloc((size_t)c->n_ghost, 8);
+    } catch (const Error &e) {
+        local = e;
+    } catch (const std::exception &e) {
+        local = Error{SPK_ERR_NOMEM, e.what()};
+    }
+    agree_or_fail(c, local.code ? &local : nullptr, "A00 (halo plan)");
     c->comm->setup_halo(c->n_ghost, c->peers, c->send_off, c->recv_off);  // collective
     c->have_A = true;
     c->pc_ready = false;
@@ -306,8 +358,19 @@ void set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, in
     if (nrows_local < 0) fail(SPK_ERR_ARG, "set_block: negative row count");
     c->ensure_scratch();
     if (which == SPK_BLOCK_A00) set_block_A(c, row_begin, nrows_local, ncols_global, rowptr, colidx, val);
-    else if (which == SPK_BLOCK_A10) set_block_B(c, nrows_local, ncols_global, rowptr, colidx, val);
-    else fail(SPK_ERR_ARG, "set_block: unknown block %d", which);
+    else if (which == SPK_BLOCK_A10) {
+        // no collective inside, but every rank sets its column slice: agree on the outcome so that a rank
+        // whose slice was refused does not leave the others to run into the next collective alone
+        Error local{0, ""};
+        try {
+            set_block_B(c, nrows_local, ncols_global, rowptr, colidx, val);
+        } catch (const Error &e) {
+            local = e;
+        } catch (const std::exception &e) {
+            local = Error{SPK_ERR_NOMEM, e.what()};
+        }
+        agree_or_fail(c, local.code ? &local : nullptr, "A10");
+    } else fail(SPK_ERR_ARG, "set_block: unknown block %d", which);
 }
 
 // ---------------------------------------------------------------------------
@@ -594,6 +657,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
 
     c->ka.tentative = single ? 1 : 0;
     KrylovState st{};
+    int32_t errword = 0;
     int cycles = 0;
     for (;;) {
         // ---- cycle start: ||r|| (parity slot 1 = "iteration -1"), convergence test, v0 = r/||r|| ----
@@ -727,8 +791,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         ++cycles;
         SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
         SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipMemcpyAsync(&errword, c->errw.p, sizeof errword, hipMemcpyDeviceToHost, s));
         SPK_HIP(hipStreamSynchronize(s));
         c->comm->check(s);  // a peer that never arrived: SPK_ERR_COMM instead of a wrong answer
+        if (errword) c->check_device_error();  // a reduction that timed out: SPK_ERR_HIP, not KSP_DIVERGED_NANORINF
         if (st.done) break;
     }
     const auto t1 = std::chrono::steady_clock::now();

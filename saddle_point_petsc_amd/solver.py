@@ -128,6 +128,39 @@ class Context:
     def comm_backend(self):
         return lib.spk_comm_backend(self.h).decode()
 
+    def comm_info(self):
+        """Per-rank diagnostics of the communicator (spk_comm_get_info): backend, why the peer-store
+        backend is off if it is, window memory kind, collective counts, device-side wait times."""
+        from ._lib import CommInfo
+        ci = CommInfo()
+        self._chk(lib.spk_comm_get_info(self.h, C.byref(ci)))
+        kinds = ("allreduce_after_mdot", "allreduce_after_maxpy", "allreduce_standalone", "halo")
+        return dict(rank=ci.rank, nranks=ci.nranks, device=ci.device, backend=ci.backend.decode(),
+                    inner_backend=ci.inner_backend.decode(), peer_enabled=bool(ci.peer_enabled),
+                    window_memory={0: "uncached", 1: "fine-grained", 2: "plain"}.get(ci.window_tier, "none"),
+                    self_test_ok=bool(ci.self_test_ok),
+                    halo={0: "none", 1: "granules", 2: "bulk", 3: "inner-backend"}[ci.halo_mode],
+                    halo_fused=bool(ci.halo_fused),
+                    allreduce=dict(fused=ci.n_allreduce_fused, kernel=ci.n_allreduce_kernel, inner=ci.n_allreduce_inner),
+                    halo_exchanges=dict(fused=ci.n_halo_fused, kernel=ci.n_halo_kernel, inner=ci.n_halo_inner),
+                    # 100 MHz ticks -> microseconds, mean per wait
+                    wait_us={k: (ci.wait_ticks[i] / 100.0 / ci.wait_count[i] if ci.wait_count[i] else None)
+                             for i, k in enumerate(kinds)},
+                    wait_count={k: int(ci.wait_count[i]) for i, k in enumerate(kinds)},
+                    why=ci.why.decode())
+
+    def debug_peer_allreduce_loopback(self, vals, rounds=6):
+        """Test hook: nranks x count inputs -> nranks x count rank-ordered sums (one launch, no IPC)."""
+        vals = np.ascontiguousarray(vals, np.float64)
+        out = np.zeros_like(vals)
+        self._chk(lib.spk_debug_peer_allreduce_loopback(self.h, vals.shape[0], vals.shape[1], rounds,
+                                                        vals.reshape(-1), out.reshape(-1)))
+        return out
+
+    def debug_finish_timeout(self, timeout_ms=50):
+        """Test hook: a reduction with a partial that never arrives; raises SpkError (SPK_ERR_HIP)."""
+        self._chk(lib.spk_debug_finish_timeout(self.h, timeout_ms))
+
     def set_block(self, which, A):
         nrows = A.nrows
         self._chk(lib.spk_set_block(self.h, which, A.row_begin if which == BLOCK_A00 else 0, nrows,

@@ -1,0 +1,280 @@
+"""BASELINE.json's configs at (or near) their real sizes, through the C ABI, against the CPU oracle
+(parity unpinned: the reference holds no fixtures):
+
+  config 2   256 x 256, K = A, FGMRES(30) + Jacobi -- the reference as written (SaddlePointProblem.c:66)
+  config 4   1024 x 1024 saddle system in row slabs: 4 and 6 PROCESSES sharing this GPU over real HIP-IPC
+             windows, 8 logical ranks in one process (the 128-node-line slabs of the 8-GPU run), and the
+             8-lane all-reduce window played by 8 workgroups of one launch
+  config 5   3-D z-slabs whose node plane takes the bulk halo form by itself; one rank's 256 x 256 x 32
+             share of the 256^3 grid (true residual = recurrence, linearity)
+
+The GPU box admits at most six processes on the card at once (gpurun's process guard), so eight
+PROCESSES cannot be run here; lanes 6 and 7 of the all-reduce window are reached by the loop-back test.
+Also here: execution failures surface as errors (reduction time-out, collective set-up failure)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_TOL = 1e-13
+
+
+# --------------------------------------------------------------------------- config 2
+@pytest.fixture(scope="module")
+def cfg2(spk, oracle):
+    A, f = spk.AssembleOperator_Laplace(256)
+    xo, io = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, rtol=1e-5, threads=8)
+    _, it = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, rtol=1e-30, max_it=45, threads=8)
+    return A, f, xo, io, it
+
+
+@pytest.mark.parametrize("fused,single", [(1, 0), (0, 0), (1, 1)])
+def test_config2_256_jacobi_fgmres(spk, oracle, cfg2, fused, single):
+    """256 x 256 grid, K = A, -pc_type jacobi, FGMRES(30): to rtol 1e-5 (the oracle needs 3475
+    iterations) and 45 truncated iterations, on the head-kernel path (fused), the step-by-step path
+    and the single-reduction route."""
+    A, f, xo, io, it = cfg2
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.pc_setup(spk.PC_JACOBI)
+        x, info = c.fgmres(f, rtol=1e-5, fused=fused, single_reduce=single)
+        _, tr = c.fgmres(f, rtol=1e-30, max_it=45, fused=fused, single_reduce=single)
+    assert info["reason"] == io["reason"] == 2
+    # single reduction: a convergence seen by the recurrence is only confirmed at the next restart
+    lo, hi = (-2, 30) if single else (-max(2, io["its"] // 100), max(2, io["its"] // 100))
+    assert lo <= info["its"] - io["its"] <= hi
+    r = np.linalg.norm(f - oracle.spmv(A, x))
+    assert r <= 1.0001e-5 * np.linalg.norm(f) and r == pytest.approx(info["rnorm"], rel=1e-6)
+    assert relerr(x, xo) < 1e-5                      # both stop at rtol 1e-5
+    assert tr["its"] == it["its"] == 45 and tr["reason"] == it["reason"] == -3
+    assert np.allclose(tr["history"], it["history"], rtol=1e-4 if single else 1e-7)
+
+
+# --------------------------------------------------------------------------- config 4
+def _launch_slab_worker(tmp_path, P, prm, port, env_extra=None, timeout=500):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(P),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tests", "_slab_worker.py"), str(tmp_path), json.dumps(prm)],
+                         capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    return ([np.load(tmp_path / f"rank{r}.npz") for r in range(P)],
+            [json.load(open(tmp_path / f"rank{r}.json")) for r in range(P)])
+
+
+@pytest.fixture(scope="module")
+def cfg4(spk, oracle):
+    A, f = spk.AssembleOperator_Laplace(1024)
+    B, g = spk.AssembleOperator_Constraints(1024)
+    rhs = np.concatenate([f, g])
+    _, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=0.0, abstol=0.0, max_it=45, threads=8)
+    xin = np.concatenate([np.sin(0.37 * np.arange(A.nrows)), 0.5 + np.arange(4)])
+    return A, B, rhs, io, xin, oracle.apply_K(A, B, xin)
+
+
+def _check_cfg4(oracle, cfg4, parts, hist_tol=1e-7):
+    """parts: per rank (b, e, y, x, kx, hist, its, reason, rnorm)."""
+    A, B, rhs, io, xin, y_ref = cfg4
+    n = A.nrows
+    y = np.zeros(n + 4); x = np.zeros(n + 4); kx = np.zeros(n + 4)
+    for (b, e, yr, xr, kxr, hist, its, reason, rnorm) in parts:
+        y[b:e], x[b:e], kx[b:e] = yr[:e - b], xr[:e - b], kxr[:e - b]
+        y[n:], x[n:], kx[n:] = yr[-4:], xr[-4:], kxr[-4:]
+        assert its == 45 and reason == -3
+        assert np.array_equal(hist, parts[0][5])                  # every rank takes the same branch: same bits
+        assert np.array_equal(xr[-4:], parts[0][3][-4:])          # multipliers replicated bit for bit
+    assert relerr(y, y_ref) < KERNEL_TOL
+    assert np.allclose(parts[0][5], io["history"], rtol=hist_tol)                 # 45 iterations against the oracle
+    r_dev = np.linalg.norm(rhs - kx)                                              # true residual, device products
+    r_ora = np.linalg.norm(rhs - oracle.apply_K(A, B, x))                         # and by the oracle
+    assert r_dev == pytest.approx(parts[0][8], rel=1e-6) and r_ora == pytest.approx(parts[0][8], rel=1e-6)
+
+
+@pytest.mark.parametrize("P", [4, 6])
+def test_config4_1024_row_slabs_across_processes(spk, oracle, cfg4, tmp_path, P):
+    """The 1024 x 1024 saddle system split over P PROCESSES that share this GPU (slabs of 256 / 170-171
+    node lines), peer-store collectives over real HIP-IPC windows: 45 iterations, identical history on
+    all ranks, history against the oracle to 1e-7, true residual = recurrence; also the single-reduction
+    route.  P = 6 is the most this box admits (process guard); it reaches all-reduce lanes 4 and 5."""
+    prm = dict(dim=2, grid=[1024, 1024], solves={"cgs": dict(rtol=0.0, abstol=0.0, max_it=45),
+                                                 "single": dict(rtol=0.0, abstol=0.0, max_it=45, single_reduce=1)})
+    R, info = _launch_slab_worker(tmp_path, P, prm, 29700 + P)
+    for name, tol in (("cgs", 1e-7), ("single", 1e-4)):
+        parts = [(int(R[r]["range"][0]), int(R[r]["range"][1]), R[r]["y"], R[r][name + "/x"], R[r][name + "/kx"],
+                  R[r][name + "/hist"], int(R[r][name + "/meta"][0]), int(R[r][name + "/meta"][1]),
+                  float(R[r][name + "/rnorm"][0])) for r in range(P)]
+        _check_cfg4(oracle, cfg4, parts, tol)
+    for r in range(P):
+        d = info[r]
+        assert d["backend"] == "peer-store" and d["peer_enabled"] and d["self_test_ok"] and d["rank"] == r
+        assert d["halo"] == "granules" and d["halo_fused"]
+        assert d["allreduce"]["fused"] >= 2 * 45 and d["allreduce"]["inner"] == 0 and d["halo_exchanges"]["inner"] == 0
+        assert d["wait_count"]["allreduce_after_mdot"] >= 45 and d["wait_us"]["allreduce_after_mdot"] is not None
+
+
+def test_config4_1024_eight_logical_ranks(spk, oracle, cfg4):
+    """The 8-way split itself (slabs of 128 node lines, the kernel shapes of one rank of the 8-GPU run,
+    the 8-way halo plan): eight logical ranks of ONE process, collectives staged through the host."""
+    from test_gpu_parity import _run_ranks
+    A, B, rhs, io, xin, y_ref = cfg4
+    out = _run_ranks(spk, 8, 1024, 1024, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=0.0, abstol=0.0, max_it=45)
+    n = A.nrows
+    x = np.zeros(n + 4)
+    for (b, e, yr, zr, xr, info, sz) in out:
+        assert e - b == 2 * 1024 * 128 and sz["n_ghost"] == 2 * 1024 * ((b > 0) + (e < n))
+        assert info["its"] == 45 and np.array_equal(info["history"], out[0][5]["history"])
+        x[b:e], x[n:] = xr[:-4], xr[-4:]
+    assert np.allclose(out[0][5]["history"], io["history"], rtol=1e-7)
+    assert np.linalg.norm(rhs - oracle.apply_K(A, B, x)) == pytest.approx(out[0][5]["rnorm"], rel=1e-6)
+
+
+@pytest.mark.parametrize("P,count", [(8, 64), (8, 35), (5, 1), (2, 7)])
+def test_peer_allreduce_window_all_lanes(spk, P, count):
+    """The all-reduce window for up to kPeerMax = 8 ranks, played by P workgroups of one launch through
+    P windows of this process: every rank must hold the same bits, equal to the rank-ordered sum."""
+    rng = np.random.default_rng(P * 100 + count)
+    vals = rng.standard_normal((P, count)) * np.exp(rng.uniform(-20, 20, (P, count)))
+    with spk.Context(0) as c:
+        out = c.debug_peer_allreduce_loopback(vals, rounds=6)
+    ref = np.zeros(count)
+    for r in range(P):                      # rank order, one addition at a time
+        ref = ref + vals[r]
+    for r in range(P):
+        assert np.array_equal(out[r], ref), r
+
+
+# --------------------------------------------------------------------------- config 5
+def test_config5_3d_zslabs_bulk_halo_across_processes(spk, oracle, tmp_path):
+    """96 x 96 x 24 nodes in two z-slabs (two processes): the node plane is 27 648 doubles, beyond the
+    8192 of a granule exchange, so the halo takes the BULK form by itself (no SPK_PEER_HALO_MAX).  SpMV
+    against the oracle (bitwise away from the slab boundary), FGMRES with the FP32 inner solve."""
+    grid = (96, 96, 24)
+    prm = dict(dim=3, grid=list(grid), saddle=False, inner=3,
+               solves={"fp32": dict(rtol=0.0, abstol=0.0, max_it=40)})
+    R, info = _launch_slab_worker(tmp_path, 2, prm, 29711)
+    A, f = spk.AssembleOperator_Laplace3D(*grid)
+    Ao = oracle.CSR(A.rowptr, A.colidx, A.val, A.ncols)
+    n = A.nrows
+    xin = np.sin(0.37 * np.arange(n))
+    y_ref = oracle.spmv(Ao, xin)
+    _, io = oracle.fgmres(Ao, f, pc_type=oracle.PC_JACOBI, rtol=0.0, abstol=0.0, max_it=40, inner_its=3, inner_omega=0.8,
+                          threads=8)
+    y = np.zeros(n); x = np.zeros(n); kx = np.zeros(n)
+    for r in range(2):
+        b, e = R[r]["range"]
+        y[b:e], x[b:e], kx[b:e] = R[r]["y"], R[r]["fp32/x"], R[r]["fp32/kx"]
+        assert info[r]["backend"] == "peer-store" and info[r]["halo"] == "bulk" and info[r]["halo_exchanges"]["inner"] == 0
+        assert np.array_equal(R[r]["fp32/hist"], R[0]["fp32/hist"]) and R[r]["fp32/meta"][0] == 40
+    plane = 3 * grid[0] * grid[1]
+    cut = int(R[0]["range"][1])
+    away = np.ones(n, bool)
+    away[cut - plane:cut + plane] = False                       # rows with off-rank columns add them last
+    assert np.array_equal(y[away], y_ref[away]) and relerr(y, y_ref) < KERNEL_TOL
+    assert np.allclose(R[0]["fp32/hist"], io["history"], rtol=1e-5)     # FP32 inner sweeps, two slabs vs one
+    assert np.linalg.norm(f - kx) == pytest.approx(float(R[0]["fp32/rnorm"][0]), rel=1e-6)
+    assert np.linalg.norm(f - oracle.spmv(Ao, x)) == pytest.approx(float(R[0]["fp32/rnorm"][0]), rel=1e-6)
+
+
+def test_config5_slab_256x256x32_properties(spk, oracle):
+    """One rank's share of the 256^3 grid split 8 ways in z (6.29 M rows, 0.5 G stored non-zeros, 6 GB of
+    CSR -- the benched shape): size-independent properties.  True residual of the iterate = the
+    device's recurrence, K linear, and the product itself against the oracle."""
+    grid = (256, 256, 32)
+    A, f = spk.AssembleOperator_Laplace3D(*grid, nthreads=16)
+    Ao = oracle.CSR(A.rowptr, A.colidx, A.val, A.ncols)
+    n = A.nrows
+    assert n == 3 * 256 * 256 * 32
+    xin = np.sin(0.37 * np.arange(n))
+    e = np.random.default_rng(5).uniform(-1, 1, n)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        y = c.mult(xin)
+        assert relerr(c.mult(2 * xin + e), 2 * y + c.mult(e)) < 1e-14
+        c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.8)
+        x, info = c.fgmres(f, rtol=0.0, abstol=0.0, max_it=35)
+        z = c.pc_apply(f)
+    assert np.array_equal(y, oracle.spmv(Ao, xin))                      # CSR-order sums: bitwise
+    assert info["its"] == 35 and info["reason"] == -3
+    assert np.linalg.norm(f - oracle.spmv(Ao, x)) == pytest.approx(info["rnorm"], rel=1e-6)
+    assert np.all(np.diff(info["history"][:31]) <= 1e-14)               # monotone inside a cycle
+    zo = oracle.pc_apply_inner(Ao, None, oracle.PC_JACOBI, 0, 3, 0.8, f)
+    assert np.array_equal(z, zo)                                        # FP32 sweeps: same float operations
+
+
+# --------------------------------------------------------------------------- execution failures are errors
+def test_reduction_timeout_is_an_execution_error(spk, oracle):
+    """A cross-workgroup reduction whose partial never arrives must come back as SPK_ERR_HIP (-2), not
+    as KSP_DIVERGED_NANORINF, and the context must stay usable (partials re-armed)."""
+    A, f = spk.AssembleOperator_Laplace(24)
+    B, g = spk.AssembleOperator_Constraints(24)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x0, i0 = c.fgmres(rhs, rtol=1e-9)
+        with pytest.raises(spk.SpkError, match="timed out") as ei:
+            c.debug_finish_timeout(40)
+        assert ei.value.code == -2
+        x1, i1 = c.fgmres(rhs, rtol=1e-9)                       # same context, afterwards
+        y = c.mult(rhs)
+    assert i1["reason"] == 2 and i1["its"] == i0["its"] and np.array_equal(x0, x1)
+    assert relerr(y, oracle.apply_K(A, B, rhs)) < KERNEL_TOL
+
+
+def test_collective_setup_failure_reaches_every_rank(spk):
+    """KSPSetOperators is collective: a rank whose local slab is refused (bad column) must not leave the
+    others waiting in the halo-plan collectives -- every rank returns an error, promptly."""
+    mx, my, P = 12, 16, 3
+    grp = spk.LocalGroup(P)
+    got = [None] * P
+
+    def work(r):
+        b, e = spk.partition_slab(mx, my, r, P)
+        A, _ = spk.AssembleOperator_Laplace(mx, my, b, e)
+        if r == 1:
+            A = spk.CSR(A.rowptr, A.colidx + 10 ** 6, A.val, A.ncols, row_begin=A.row_begin)
+        c = spk.Context(0)
+        c.comm_init_local(grp, r)
+        try:
+            c.set_block(spk.BLOCK_A00, A)
+            got[r] = (0, "")
+        except spk.SpkError as ex:
+            got[r] = (ex.code, str(ex))
+        c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=60) for t in th]
+    grp.close()
+    assert all(not t.is_alive() for t in th)
+    assert got[1][0] == -1 and "out of range" in got[1][1]
+    for r in (0, 2):
+        assert got[r][0] == -4 and "rank 1 failed" in got[r][1]
+
+
+def test_converged_default_reference_norm_on_device(spk, oracle):
+    """KSPConvergedDefault at iteration 0 as PETSc states it (oracle: test_converged_default_reference_norm):
+    non-zero guess -> ||b|| (or the initial residual when b = 0) is the reference norm for rtol AND divtol."""
+    A, f = spk.AssembleOperator_Laplace(9)
+    n = A.nrows
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.pc_setup(spk.PC_JACOBI)
+        xs, _ = c.fgmres(f, rtol=1e-13)
+        for kw, b, x0 in ((dict(rtol=1e-6), np.zeros(n), xs), (dict(rtol=1e-3, dtol=1e30), f, 1e6 * xs),
+                          (dict(rtol=1e-3), f, 1e6 * xs), (dict(rtol=1e-12, dtol=0.5), f, None)):
+            x, info = c.fgmres(b, x0=x0, **kw)
+            xo, io = oracle.fgmres(A, b, x0=x0, pc_type=oracle.PC_JACOBI, **kw)
+            assert info["reason"] == io["reason"] and abs(info["its"] - io["its"]) <= 1, (kw, info, io)
+            if info["reason"] > 0:
+                assert relerr(x, xo) < 1e-6 or np.linalg.norm(x - xo) < 1e-6 * np.linalg.norm(xs)

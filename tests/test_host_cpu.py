@@ -299,8 +299,19 @@ def test_ksp_options_follow_the_petsc_names(spk):
     k.setFromOptions("-ksp_max_it 7 -ksp_rtol 1e-3")
     assert k.getOptions()[0].max_it == 7
     # call order errors, as PETSc raises them
-    with pytest.raises(spk.SpkError):
+    with pytest.raises(spk.SpkError, match="KSPSetOperators"):
         k.setUp()                                   # no operators yet
+    k.destroy()
+    # no silent defaults: PETSc would pick gmres / ilu, which do not exist here (include/spk_ksp.h)
+    k = spk.KSP()
+    k.setFromOptions("-ksp_rtol 1e-3")
+    with pytest.raises(spk.SpkError, match="-ksp_type fgmres") as ei:
+        k.setUp()
+    assert ei.value.code == -6
+    k.setFromOptions("-ksp_type fgmres")
+    with pytest.raises(spk.SpkError, match="-pc_type jacobi") as ei:
+        k.setUp()
+    assert ei.value.code == -6
     k.destroy()
     assert spk.lib.SpkKSPConvergedReasonName(2) == b"CONVERGED_RTOL"
     assert spk.lib.SpkKSPConvergedReasonName(-3) == b"DIVERGED_ITS"

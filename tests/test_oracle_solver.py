@@ -168,3 +168,25 @@ def test_fgmres_history_matches_textbook_restatement(oracle, pc, fact, restart):
     k = min(len(hist), len(info["history"]), 2 * restart)
     assert np.allclose(info["history"][:k], hist[:k], rtol=1e-7)
     assert relerr(x, xt) < 1e-8
+
+
+def test_converged_default_reference_norm(oracle):
+    """KSPConvergedDefault at iteration 0 (PETSc iterativ.c, as published; parity unpinned: nothing in
+    the reference pins it): zero guess -> tolerances relative to the initial residual; non-zero guess ->
+    relative to ||b||, or to the initial residual when b = 0; -ksp_divtol compares against the same norm."""
+    A, f = oracle.assemble(9)
+    n = A.nrows
+    xs = sla.spsolve(A.to_scipy().tocsc(), f)
+    # b = 0 with a non-zero guess: the solve must iterate towards x = 0 (ttol = rtol * ||r0||, not abstol)
+    x, info = oracle.fgmres(A, np.zeros(n), x0=xs, pc_type=oracle.PC_JACOBI, rtol=1e-6)
+    assert info["reason"] == 2 and info["its"] > 0
+    assert info["rnorm"] <= 1e-6 * info["rnorm0"] and np.linalg.norm(x) < 1e-5 * np.linalg.norm(xs)
+    # non-zero guess, b != 0: relative to ||b||, not to the (much larger) initial residual
+    x, info = oracle.fgmres(A, f, x0=1e6 * xs, pc_type=oracle.PC_JACOBI, rtol=1e-3, dtol=1e30)
+    assert info["reason"] == 2 and info["rnorm"] <= 1e-3 * np.linalg.norm(f) < 1e-3 * info["rnorm0"]
+    # the divergence test refers to ||b|| too: an initial residual 1e6 times ||b|| is "diverged" at once
+    x, info = oracle.fgmres(A, f, x0=1e6 * xs, pc_type=oracle.PC_JACOBI, rtol=1e-3)       # default divtol 1e4
+    assert info["reason"] == -4 and info["its"] == 0
+    # zero guess: DTOL can only come from growth during the iteration; a tiny divtol triggers it at iteration 0
+    x, info = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, rtol=1e-12, dtol=0.5)
+    assert info["reason"] == -4 and info["its"] == 0
