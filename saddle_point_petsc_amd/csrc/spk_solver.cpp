@@ -127,6 +127,10 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
 
     split_csr(row_begin, nrows_local, rowptr, colidx, val, sp, ncols_global);  // threaded, validates the columns
     if (sp.bad_column) fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", sp.bad_value, (long long)ncols_global);
+    // validation passed: from here on the previous operator is being replaced (a refused block, above,
+    // leaves it in place and usable)
+    c->have_A = false;
+    c->pc_ready = false;
     c->n_global = ncols_global;
     c->row_begin = row_begin;
     c->n_local = nrows_local;
@@ -208,7 +212,6 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     } catch (const std::exception &e) {
         local = Error{SPK_ERR_NOMEM, e.what()};
     }
-    c->have_A = false;
     agree_or_fail(c, local.code ? &local : nullptr, "A00");
 
     // ---- halo plan (VecScatter of MatMult_MPIAIJ) ----
@@ -724,7 +727,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 }
                 c->comm->allreduce_sum(nb, nn, s);
             } else if (single) {
-                const k::PeerAR ar = loc + 1 + m <= 40 ? c->comm->fused_allreduce(loc + 2 + m) : k::PeerAR{};
+                const k::PeerAR ar = loc + 1 + m <= 40 ? c->comm->fused_allreduce(loc + 2 + m, k::kStatArDots) : k::PeerAR{};
                 // B D w from the same pass: the dense rows, or two halves per parity-interleaved plane
                 const bool spl = bpk && loc + 1 + m <= 40;
                 k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, spl ? c->bdpk.p : c->bd.p, m, spl ? 1 : 0);
@@ -749,10 +752,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             } else {
                 // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
                 // across ranks the all-reduces ride in the finish of the two kernels (peer-store backend)
-                const k::PeerAR ar1 = loc + 1 <= 40 ? c->comm->fused_allreduce(loc + 2) : k::PeerAR{};
+                const k::PeerAR ar1 = loc + 1 <= 40 ? c->comm->fused_allreduce(loc + 2, k::kStatArDots) : k::PeerAR{};
                 k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar1), done, s);
                 if (!ar1.P) c->comm->allreduce_sum(db, loc + 2, s);
-                const k::PeerAR ar2 = c->comm->fused_allreduce(nn);
+                const k::PeerAR ar2 = c->comm->fused_allreduce(nn, k::kStatArNorm);
                 k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nb, ar2), done, s, bdp, ld, nl, m,
                          fused ? w1side : nullptr, nullptr, bpk);
                 if (!ar2.P) c->comm->allreduce_sum(nb, nn, s);
