@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--inner-sweeps", type=int, default=0, help="FP32 damped-Jacobi Richardson sweeps standing for "
                                                                 "diag(A)^-1 in the PC (BASELINE config 5's mixed FP32 inner solve)")
     ap.add_argument("--inner-omega", type=float, default=0.8)
+    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2],
+                    help="opts.iteration_form: 0 auto (two launches per iteration below ~1 M local rows), 1 four launches, 2 two launches")
     ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
     args = ap.parse_args()
 
@@ -212,7 +214,8 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
-    kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300, single_reduce=args.single_reduce)
+    kw = dict(restart=args.restart, rtol=0.0, abstol=0.0, dtol=1e300, single_reduce=args.single_reduce,
+              iteration_form=args.iter_form)
 
     def timed_solve(steps, **kws):
         """exactly `steps` iterations between two barriers; MAX over ranks of the wall time"""
@@ -338,7 +341,7 @@ def main():
                                + (f"saddle K=[A B^T;B 0] with {B.nrows} constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (B.nrows if saddle else 0), "dim": args.dim, "pc": args.pc, "restart": args.restart,
-                   "inner_fp32_sweeps": args.inner_sweeps,
+                   "inner_fp32_sweeps": args.inner_sweeps, "iteration_form": args.iter_form,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",

@@ -104,8 +104,17 @@ typedef struct spk_opts {
                                residual computed at the restart confirms it, never on the
                                recurrence alone.  Needs restart + m <= 63 (falls back to two
                                reductions otherwise). */
-    int32_t reserved[2];
+    int32_t iteration_form; /* how the head-kernel paths launch one classical Gram-Schmidt iteration (same
+                               algorithm, two reductions, norms taken from w' itself):
+                               SPK_ITER_AUTO (0): two launches below ~1 M local rows, four above;
+                               SPK_ITER_FOUR_LAUNCH (1): head, SpMV, MDot, MAXPY;
+                               SPK_ITER_TWO_LAUNCH (2): SpMV with MDot in its tile epilogues (VecScale of v and z
+                               folded in), MAXPY with the norm and the next iteration's preconditioner + B^T
+                               product on the un-normalised vector (B D w' by linearity from B D w).  Needs
+                               the 2x2-blocked matrix layout and restart + m <= 62; otherwise four launches. */
+    int32_t reserved;
 } spk_opts;
+enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2 };
 
 typedef struct spk_result {
     int32_t its;            /* KSPGetIterationNumber   */

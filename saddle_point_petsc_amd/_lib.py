@@ -28,7 +28,7 @@ class Opts(C.Structure):
         ("restart", C.c_int32), ("max_it", C.c_int32), ("rtol", C.c_double),
         ("abstol", C.c_double), ("dtol", C.c_double), ("guess_nonzero", C.c_int32),
         ("orthog", C.c_int32), ("check_every", C.c_int32), ("fused", C.c_int32),
-        ("cgs_refine", C.c_int32), ("single_reduce", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("cgs_refine", C.c_int32), ("single_reduce", C.c_int32), ("iteration_form", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

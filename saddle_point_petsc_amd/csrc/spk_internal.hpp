@@ -96,6 +96,7 @@ struct BcsrDev {
     DevBuf<int32_t> tile_brow;
     int32_t ntiles = 0;
     bool ok = false;
+    bool long_rows = false;  // a block row longer than one tile exists (the two-launch iteration does not take those)
 };
 
 // Short-and-wide block (B: m rows x n_local cols) cut into column windows so
@@ -266,6 +267,7 @@ namespace k {
 constexpr int kMaxNv = 64;       // max vectors in one mdot/maxpy launch (restart <= 63)
 constexpr int kPartialLd = 64;   // leading dimension of block partials
 constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
+constexpr int kBTile = 512;      // 2x2 blocks per tile of the blocked SpMV kernels
 
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row);
 // arms the block-partials buffer of the cross-workgroup finish (spk_kernels.hip)
@@ -395,6 +397,72 @@ struct KrylovArrays {
     int32_t hist_cap, ldh;
     int32_t tentative;  // 1: the recurrence may end a cycle, only a true residual may end the solve
 };
+// ---- two-launch iteration (spk_kernels.hip, "Two-launch iteration") ----
+// kernel A: w = s (A z~ + c~), v and z normalised on the way, h = V^T w and q = B D w from the tile epilogues
+struct IterA {
+    // 2x2-blocked matrix and its tiling
+    const int32_t *browptr, *bcol;
+    const double *vtop, *vbot;
+    const int32_t *tile_brow;
+    int ntiles, tiles_per_xcd, slots;  // slots: workgroups per XCD (iter_slots)
+    OffDiag od;
+    // vectors
+    const double *zsrc;  // gathered: z~ (un-normalised, from kernel B) or Z_0 (first iteration of a cycle)
+    double *zdst;        // Z_loc = s z~ (nrm2 != nullptr)
+    double *vcur;        // V_loc: normalised in place (nrm2 != nullptr)
+    double *w;           // V_{loc+1}: in c~ when acc, out w
+    int acc;
+    const double *nrm2;  // ||w'||^2 of the previous iteration: s = 1/sqrt(nrm2[0]); nullptr: s = 1, operands normalised
+    const double *V;     // basis V_0 .. V_{nv-1} (V_{nv-1} = vcur)
+    int64_t ldv;
+    int nv;
+    const double *bd;    // B D: m dense rows or m/2 parity-interleaved planes (nullptr with m = 0)
+    int64_t ldb;
+    int m, packed;
+    int64_t nl;
+    int lam_in_dot;      // this rank counts the m multiplier entries in inner products (rank 0)
+    double *tb;          // B D v_i per basis vector, (restart+2) x 8
+    double *wl_out;      // side copy of the multiplier entries of w for kernel B
+    // finish: [h_0..h_{nv-1}, q_0..q_{m-1}]
+    double *partials, *out;
+    PeerAR ar;
+    int32_t *err;
+    uint32_t fin_ticks;
+    // Givens step of the previous iteration (loc_prev < 0: none)
+    KrylovArrays ka;
+    int loc_prev;
+    const double *dots_prev, *nrm_prev;
+    const int32_t *done;
+};
+// kernel B: w' = w - V h, ||w'||^2, and the next iteration's PC / B^T product on the un-normalised w'
+struct IterB {
+    const double *V;
+    int64_t ldv;
+    int nv;
+    const double *dots;  // reduced [h, q]
+    double *tb;
+    double *w;           // V_{loc+1}: in w, out w'
+    const double *dinv, *bd;
+    int64_t ldb;
+    const double *shat, *gram;
+    int fact;
+    int64_t nl;
+    int m, packed;
+    double *zun;         // out: z~
+    double *c;           // out: c~ = pre-load of the next product (V_{loc+2}); nullptr with m = 0
+    const double *wl_in;
+    int lam_in_dot;
+    double *partials, *out;  // out[0] = ||w'||^2
+    PeerAR ar;
+    int32_t *err;
+    uint32_t fin_ticks;
+    SendRanges sr;
+    int gmain;           // set by the launcher
+    const int32_t *done;
+};
+void iter_spmv_mdot(const IterA &a, hipStream_t s);
+void iter_maxpy_uhead(IterB b, hipStream_t s);
+int iter_slots(int tiles_per_xcd);
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
 void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0);
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
@@ -484,6 +552,7 @@ struct spk_ctx {
     // Krylov workspace (sized by restart)
     int ws_restart = -1;
     spk::DevBuf<double> V, Z, xsol, rhs, tmp;
+    spk::DevBuf<double> zun;    // z~ of the two-launch iteration (un-normalised M^-1 w')
     spk::DevBuf<double> kry_d;  // H, cc, ss, rs, nrs, hcol, hist
     spk::DevBuf<spk::KrylovState> kst;
     spk::k::KrylovArrays ka{};

@@ -413,8 +413,7 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 // block land in LDS as (a00 x0, a01 x1, a10 x0, a11 x1); row 2k adds its pairs in block
 // order = CSR order, so the result is bit-identical to the CSR kernel and the oracle.
 // ---------------------------------------------------------------------------
-// blocks per tile (2048 stored non-zeros); measured 256: 63.6 us, 512: 61.3 us, 1024: 76.2 us
-constexpr int kBTile = 512;
+// blocks per tile (kBTile = 512 in spk_internal.hpp: 2048 stored non-zeros); measured 256: 63.6 us, 512: 61.3 us, 1024: 76.2 us
 
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow)
 {
@@ -2347,6 +2346,462 @@ void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double
         else SPK_MH(256, 8, 1, 8);
     }
 #undef SPK_MH
+}
+
+// ---------------------------------------------------------------------------
+// Two-launch iteration (opts.iteration_form; the default below ~1 M rows, i.e. for a rank's slab of a
+// strong-scaling run and the 256^2 / 512^2 grids).  On such vectors every kernel of the four-launch
+// iteration costs ~5 us beyond its bytes (launch boundary, first-load latency, publish -> re-read of
+// the reduction): 45-50 us against a 27 us byte floor on the 1/8 slab of the 1024^2 grid.  Same
+// algorithm -- classical Gram-Schmidt with the norm taken directly from w', two reductions -- in TWO
+// launches:
+//
+//   A  iter_spmv_mdot_kernel   w = s (A z~ + c~) row tile by row tile, and in the tile's epilogue, while
+//                              its w values sit in LDS, their share of h = V^T w and q = B D w (VecMDot
+//                              costs no launch and no second pass over w).  s = 1/||w'|| of the previous
+//                              iteration: the normalisation (VecScale) of v and z rides here too.
+//   B  iter_maxpy_uhead_kernel w' = w - V h (VecMAXPY) with ||w'||^2 from the same pass (VecNorm), and the
+//                              next iteration's preconditioner and B^T product applied to the
+//                              UN-normalised w' (both are linear): z~ = D w' - (B D)^T y~, c~ = B^T y~.
+//                              y~ needs t~ = B D w', a reduction over the very vector this pass builds;
+//                              it follows from q by linearity, t~ = q - sum_i h_i (B D v_i) -- an
+//                              identity between sums of the same magnitude (no squares: none of the
+//                              Pythagorean norm's cancellation), kept per basis vector in tb[].
+//
+// Workgroups keep their row tiles through a whole launch; the LAST workgroup streams nothing: it holds
+// the m multiplier entries, runs the Givens step of the previous iteration while the others stream,
+// and is the reducer (and the all-reducer across ranks) of the launch.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ld1nt(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double inv_norm(double nrm2)
+{
+    const double tt = sqrt(nrm2);
+    return tt > 1e-300 ? 1.0 / tt : 1.0;
+}
+
+template <int VW>
+__global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
+{
+    if (*a.done) return;
+    __shared__ double prod[kBTile * 4];
+    __shared__ double wt[kThreads], vt[kThreads];
+    const double scale = a.nrm2 ? inv_norm(a.nrm2[0]) : 1.0;
+    const int nmain = 8 * a.slots;
+    const int nv = a.nv, m = a.m;
+    if ((int)blockIdx.x == nmain) {
+        // ---- the scalar / reducing workgroup
+        double *lamw = wt;
+        if ((int)threadIdx.x < m) {
+            const int r = threadIdx.x;
+            double wl;
+            if (a.nrm2) {  // normalise what kernel B left un-normalised
+                a.vcur[a.nl + r] *= scale;
+                a.zdst[a.nl + r] = a.zsrc[a.nl + r] * scale;
+                wl = a.w[a.nl + r] * scale;
+                a.w[a.nl + r] = wl;
+                a.tb[(size_t)(nv - 1) * 8 + r] *= scale;
+            } else {
+                wl = a.w[a.nl + r];
+            }
+            a.wl_out[r] = wl;
+            lamw[r] = wl;
+        }
+        __syncthreads();
+        if (a.loc_prev >= 0) givens_block(a.ka, a.loc_prev, a.dots_prev, a.nrm_prev);
+        __syncthreads();
+        const int k = nv + m;
+        final_reduce(a.partials, nmain, kPartialLd, k, prod, FinErr{a.err, a.fin_ticks});
+        if (a.lam_in_dot && (int)threadIdx.x < nv) {  // multiplier entries of the inner products (rank 0 only)
+            double sl = 0.0;
+            for (int r = 0; r < m; ++r) sl += a.V[(size_t)threadIdx.x * a.ldv + a.nl + r] * lamw[r];
+            prod[threadIdx.x] += sl;
+        }
+        __syncthreads();
+        if (a.ar.P) peer_allreduce_block(a.ar, prod, k, a.out);
+        else if ((int)threadIdx.x < k) a.out[threadIdx.x] = prod[threadIdx.x];
+        return;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = a.packed ? m / 2 : m;  // streams of B D: dense rows, or parity-interleaved planes
+    const int nvt = nv + np;
+    const int per = (nvt + 3) >> 2;
+    const int v0 = wave * per;
+    const int cnt = (nvt - v0) < per ? (nvt - v0) : per;  // <= 0: a wave without vectors
+    double acc[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[i] = 0.0;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    for (int tl = slot; tl < a.tiles_per_xcd; tl += a.slots) {
+        const int t = xcd * a.tiles_per_xcd + tl;
+        if (t >= a.ntiles) break;
+        const int br0 = a.tile_brow[t], br1 = a.tile_brow[t + 1];
+        const int b0 = a.browptr[br0], b1 = a.browptr[br1];
+        const int cntb = b1 - b0;
+        // phase 1: the tile's matrix stream, x gathered 16 bytes at a time (as spmv_bcsr_kernel)
+        constexpr int kSteps = kBTile / kThreads;
+        int c[kSteps];
+        double2 tp[kSteps], bo[kSteps];
+#pragma unroll
+        for (int i = 0; i < kSteps; ++i) {
+            const int q = i * kThreads + threadIdx.x;
+            if (q < cntb) {
+                c[i] = __builtin_nontemporal_load(a.bcol + b0 + q);
+                tp[i] = ld2s<true>(a.vtop, b0 + q);
+                bo[i] = ld2s<true>(a.vbot, b0 + q);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kSteps; ++i) {
+            const int q = i * kThreads + threadIdx.x;
+            if (q < cntb) {
+                const double2 xv = reinterpret_cast<const double2 *>(a.zsrc)[c[i]];
+                double2 p0, p1;
+                p0.x = tp[i].x * xv.x;
+                p0.y = tp[i].y * xv.y;
+                p1.x = bo[i].x * xv.x;
+                p1.y = bo[i].y * xv.y;
+                *reinterpret_cast<double2 *>(prod + 4 * q) = p0;
+                *reinterpret_cast<double2 *>(prod + 4 * q + 2) = p1;
+            }
+        }
+        __syncthreads();
+        // phase 2: one thread per row, CSR order; scaling and normalisation of the row's entries
+        const int nr = 2 * (br1 - br0), r0 = 2 * br0;
+        const int lr = threadIdx.x;
+        if (lr < nr) {
+            const int br = br0 + (lr >> 1), half = lr & 1;
+            const int k0 = a.browptr[br] - b0, k1 = a.browptr[br + 1] - b0;
+            double sr = 0.0;
+            for (int k = k0; k < k1; ++k) {
+                const double2 p = *reinterpret_cast<const double2 *>(prod + 4 * k + 2 * half);
+                sr += p.x;
+                sr += p.y;
+            }
+            const int r = r0 + lr;
+            if (a.od.rowptr)
+                for (int k = a.od.rowptr[r]; k < a.od.rowptr[r + 1]; ++k) sr += a.od.val[k] * a.od.xg[a.od.colidx[k]];
+            if (a.acc) sr += a.w[r];
+            const double wv = sr * scale;
+            a.w[r] = wv;
+            wt[lr] = wv;
+            if (a.nrm2) {
+                const double vn = a.vcur[r] * scale;
+                a.vcur[r] = vn;
+                vt[lr] = vn;
+                a.zdst[r] = a.zsrc[r] * scale;
+            }
+        }
+        __syncthreads();
+        // phase 3: this tile's share of V^T w and B D w; the waves split the VECTORS, lane k owns rows k, k+64, ..
+        if (cnt > 0) {
+            double wr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[j] = (lane + 64 * j) < nr ? wt[lane + 64 * j] : 0.0;
+            constexpr int G = 4;
+#pragma unroll
+            for (int g0 = 0; g0 < VW; g0 += G) {
+                if (g0 < cnt) {  // wave-uniform
+                    double av[G][4];
+#pragma unroll
+                    for (int v = 0; v < G; ++v) {
+                        const int i = v0 + g0 + v;
+                        const bool live = g0 + v < cnt;
+                        const bool fromlds = a.nrm2 && i == nv - 1;  // the vector this launch normalises: its rows are in LDS
+                        const double *src = i < nv ? a.V + (size_t)i * a.ldv : a.bd + (size_t)(i - nv) * a.ldb;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            av[v][j] = 0.0;
+                            if (64 * j < nr) {  // wave-uniform
+                                const int k = lane + 64 * j;
+                                if (live && k < nr) av[v][j] = fromlds ? vt[k] : ld1nt(src + r0 + k);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < G; ++v)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[g0 + v] += av[v][j] * wr[j];
+                }
+            }
+        }
+        __syncthreads();  // prod / wt / vt are reused by the next tile
+    }
+    // this workgroup's partial sums: value i of [h_0..h_{nv-1}, q_0..q_{m-1}] comes from exactly one wave
+    double *row = a.partials + (size_t)blockIdx.x * kPartialLd;
+#pragma unroll
+    for (int il = 0; il < VW; ++il) {
+        if (il < cnt) {  // wave-uniform
+            const int i = v0 + il;
+            if (i < nv || !a.packed) {
+                const double sdot = wave_sum(acc[il]);
+                if (lane == 0) publish(row + i, sdot);
+            } else {  // a parity-interleaved plane: even rows belong to constraint row 2 pl, odd ones to 2 pl + 1
+                const int pl = i - nv;
+                const double se = wave_sum((lane & 1) ? 0.0 : acc[il]);
+                const double so = wave_sum((lane & 1) ? acc[il] : 0.0);
+                if (lane == 0) {
+                    publish(row + nv + 2 * pl, se);
+                    publish(row + nv + 2 * pl + 1, so);
+                }
+            }
+        }
+    }
+}
+
+void iter_spmv_mdot(const IterA &a, hipStream_t s)
+{
+    const int np = a.packed ? a.m / 2 : a.m;
+    const int per = (a.nv + np + 3) / 4;
+    const dim3 grid(8 * a.slots + 1), block(kThreads);
+    if (a.nv + a.m > kMaxNv - 1) fail(SPK_ERR_ARG, "iter_spmv_mdot: %d values exceed one reduction", a.nv + a.m);
+    if (per <= 4) hipLaunchKernelGGL(iter_spmv_mdot_kernel<4>, grid, block, 0, s, a);
+    else if (per <= 8) hipLaunchKernelGGL(iter_spmv_mdot_kernel<8>, grid, block, 0, s, a);
+    else if (per <= 12) hipLaunchKernelGGL(iter_spmv_mdot_kernel<12>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(iter_spmv_mdot_kernel<16>, grid, block, 0, s, a);
+}
+
+// Workgroups a launch of kernel A runs per XCD: every slot gets the same number of tiles (+-1), all of
+// them co-resident (<= 4 workgroups of 256 threads per CU are assumed: the kernel holds up to 16
+// accumulators and 16 loads in flight per lane next to the SpMV's own registers)
+int iter_slots(int tiles_per_xcd)
+{
+    const int smax = 32 * 4;  // CUs per XCD x workgroups per CU
+    if (tiles_per_xcd <= smax) return tiles_per_xcd > 0 ? tiles_per_xcd : 1;
+    const int tpw = (tiles_per_xcd + smax - 1) / smax;
+    return (tiles_per_xcd + tpw - 1) / tpw;
+}
+
+template <int T, int G, int U, int MP>
+__global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
+{
+    if (*b.done) return;
+    __shared__ double hs[kMaxNv], lam[kMaxNv * 8], ys[8], wraws[8], tus[8];
+    __shared__ double red[T];
+    const int nv = b.nv, m = b.m;
+    // ---- scalars, derived by every workgroup from the reduced [h, q] ----
+    if (threadIdx.x < kWave) {  // lane i owns basis vector i (nv <= 63)
+        const int i = threadIdx.x;
+        const double hi = i < nv ? b.dots[i] : 0.0;
+        if (i < nv) hs[i] = hi;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < m) {  // uniform
+                const double tsum = wave_sum(i < nv ? hi * b.tb[i * 8 + r] : 0.0);
+                if (i == 0) tus[r] = b.dots[nv + r] - tsum;  // B D w' = B D w - sum h_i (B D v_i)
+            }
+        }
+    }
+    for (int t = threadIdx.x; t < nv * m; t += T) lam[t] = b.V[(size_t)(t / m) * b.ldv + b.nl + (t % m)];
+    __syncthreads();
+    if ((int)threadIdx.x < MP) {
+        const int r = threadIdx.x;
+        double y = 0.0, wraw = 0.0;
+        if (r < m) {
+            wraw = b.wl_in[r];
+            for (int i = 0; i < nv; ++i) wraw += -hs[i] * lam[i * m + r];  // the MAXPY of the multiplier entries
+            y = -(wraw - tus[r]) / b.shat[r];
+        }
+        wraws[r] = wraw;
+        ys[r] = y;
+    }
+    __syncthreads();
+    double yv[MP > 0 ? MP : 1];
+#pragma unroll
+    for (int r = 0; r < (MP > 0 ? MP : 1); ++r) yv[r] = MP > 0 ? ys[r] : 0.0;
+
+    const int gmain = b.gmain;
+    const int nhalo = b.sr.peer ? (2 * b.sr.nrecv + T - 1) / T : 0;
+    if ((int)blockIdx.x == gmain + nhalo) {
+        // ---- the scalar / reducing workgroup: multiplier entries of w', z~, c~; B D w' for the recurrence
+        if ((int)threadIdx.x < m) {
+            const int r = threadIdx.x;
+            double w1 = tus[r];
+            if (b.fact == SPK_SCHUR_FULL)
+                for (int q = 0; q < m; ++q) w1 -= b.gram[r * m + q] * ys[q];
+            b.w[b.nl + r] = wraws[r];
+            b.zun[b.nl + r] = ys[r];
+            b.c[b.nl + r] = w1;
+            b.tb[(size_t)nv * 8 + r] = tus[r];  // un-normalised; kernel A of the next iteration scales it
+        }
+        red[threadIdx.x] = 0.0;
+        __syncthreads();
+        final_reduce(b.partials, gmain, kPartialLd, 1, red, FinErr{b.err, b.fin_ticks});
+        if (threadIdx.x == 0) {
+            double tot = red[0];
+            for (int r = 0; r < m; ++r) tot += b.lam_in_dot ? wraws[r] * wraws[r] : 0.0;
+            red[0] = tot;
+        }
+        __syncthreads();
+        if (b.ar.P) peer_allreduce_block(b.ar, red, 1, b.out);
+        else if (threadIdx.x == 0) b.out[0] = red[0];
+        return;
+    }
+    const int64_t n2 = b.nl / 2;
+    if ((int)blockIdx.x >= gmain) {  // peer-store halo: unpack this rank's ghost rows (see fused_head_kernel)
+        const int64_t g = (int64_t)((int)blockIdx.x - gmain) * T + threadIdx.x;
+        if (g < 2 * (int64_t)b.sr.nrecv) {
+            uint32_t lo;
+            const unsigned long long tw0 = (b.sr.stats && threadIdx.x == 0) ? wall_clock64() : 0ull;
+            const bool ok = granule_wait(b.sr.mine + g, b.sr.seq, b.sr.timeout_ms, lo, b.sr.err, b.done);
+            if (b.sr.stats && threadIdx.x == 0) {
+                atomicAdd(b.sr.stats + 2 * kStatHalo, wall_clock64() - tw0);
+                atomicAdd(b.sr.stats + 2 * kStatHalo + 1, 1ull);
+            }
+            const uint32_t other = __shfl_xor(lo, 1, kWave);
+            if (!(g & 1)) b.sr.xghost[g >> 1] = join_halves(lo, other);
+            if (!ok) __hip_atomic_store(b.sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const int bid = blockIdx.x;
+    const int bx = b.sr.peer ? ((bid & 1) ? gmain - 1 - (bid >> 1) : (bid >> 1)) : bid;
+    double nrm = 0.0;
+    for (int64_t tile = bx; tile * (T * U) < n2; tile += gmain) {
+        double2 wv[U], dv[U], sv[U];
+        int64_t idx[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = tile * (T * U) + u * T + threadIdx.x;
+            ok[u] = idx[u] < n2;
+            if (!ok[u]) idx[u] = 0;
+            wv[u] = ld2(b.w, idx[u]);
+            dv[u] = ld2(b.dinv, idx[u]);
+            sv[u].x = sv[u].y = 0.0;
+        }
+        if (MP > 0) {
+            if (b.packed) {
+#pragma unroll
+                for (int q = 0; q < MP / 2; ++q) {
+                    if (2 * q < m) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double2 e = ld2s<true>(b.bd + (size_t)q * b.ldb, idx[u]);
+                            sv[u].x += e.x * yv[2 * q];
+                            sv[u].y += e.y * yv[2 * q + 1];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < MP; ++r) {
+                    if (r < m) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double2 e = ld2s<true>(b.bd + (size_t)r * b.ldb, idx[u]);
+                            sv[u].x += e.x * yv[r];
+                            sv[u].y += e.y * yv[r];
+                        }
+                    }
+                }
+            }
+        }
+        for (int g0 = 0; g0 < nv; g0 += G) {
+            double2 t[G][U];
+            double ai[G];
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+                const bool live = g0 + v < nv;
+                const int ic = live ? g0 + v : 0;
+                ai[v] = live ? -hs[ic] : 0.0;
+                const double *Vi = b.V + (size_t)ic * b.ldv;
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[v][u] = ld2s<true>(Vi, live ? idx[u] : 0);
+            }
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wv[u].x += ai[v] * t[v][u].x;
+                    wv[u].y += ai[v] * t[v][u].y;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u]) {
+                const int64_t i = idx[u];
+                double2 zz, cc;
+                nrm += wv[u].x * wv[u].x;
+                nrm += wv[u].y * wv[u].y;
+                zz.x = wv[u].x * dv[u].x;
+                zz.y = wv[u].y * dv[u].y;
+                if (MP > 0 && b.fact == SPK_SCHUR_FULL) {
+                    zz.x -= sv[u].x;
+                    zz.y -= sv[u].y;
+                }
+                reinterpret_cast<double2 *>(b.w)[i] = wv[u];
+                reinterpret_cast<double2 *>(b.zun)[i] = zz;
+                if (MP > 0) {
+                    cc.x = sv[u].x / dv[u].x;
+                    cc.y = sv[u].y / dv[u].y;
+                    reinterpret_cast<double2 *>(b.c)[i] = cc;
+                }
+                for (int q = 0; q < b.sr.n; ++q) {
+                    const int64_t e = 2 * i - b.sr.r0[q];
+                    if (b.sr.peer) {
+                        const unsigned long long tag = (unsigned long long)b.sr.seq << 32;
+                        if (e >= 0 && e < b.sr.len[q]) {
+                            const unsigned long long bits = (unsigned long long)__double_as_longlong(zz.x);
+                            st_sys(b.sr.remote[q] + 2 * e, tag | (bits & 0xffffffffull));
+                            st_sys(b.sr.remote[q] + 2 * e + 1, tag | (bits >> 32));
+                        }
+                        if (e + 1 >= 0 && e + 1 < b.sr.len[q]) {
+                            const unsigned long long bits = (unsigned long long)__double_as_longlong(zz.y);
+                            st_sys(b.sr.remote[q] + 2 * e + 2, tag | (bits & 0xffffffffull));
+                            st_sys(b.sr.remote[q] + 2 * e + 3, tag | (bits >> 32));
+                        }
+                    } else {
+                        if (e >= 0 && e < b.sr.len[q]) b.sr.buf[b.sr.off[q] + e] = zz.x;
+                        if (e + 1 >= 0 && e + 1 < b.sr.len[q]) b.sr.buf[b.sr.off[q] + e + 1] = zz.y;
+                    }
+                }
+            }
+        }
+    }
+    // ||w'||^2 of this workgroup's entries
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double sw = wave_sum(nrm);
+    if (lane == 0) red[wave] = sw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int j = 0; j < T / kWave; ++j) tsum += red[j];
+        publish(b.partials + (size_t)blockIdx.x * kPartialLd, tsum);
+    }
+}
+
+void iter_maxpy_uhead(IterB b, hipStream_t s)
+{
+    const int64_t n2 = b.nl / 2;
+    // thin workgroups below 0.5 M entries (as MAXPY), fat ones above
+    const bool thin = n2 < (int64_t)kVecMaxBlocks * 2048;
+    const int T = thin ? 256 : 512, U = thin ? (n2 < (int64_t)kVecMaxBlocks * 1024 ? 1 : 2) : 4;
+    int64_t tiles = (n2 + (int64_t)T * U - 1) / ((int64_t)T * U);
+    if (tiles < 1) tiles = 1;
+    b.gmain = (int)std::min<int64_t>(tiles, thin ? 1024 : kVecMaxBlocks);
+    int grid = b.gmain + 1;
+    if (b.sr.peer) grid += (2 * b.sr.nrecv + T - 1) / T;
+    if (b.nv + b.m > kMaxNv - 1) fail(SPK_ERR_ARG, "iter_maxpy_uhead: %d values exceed one reduction", b.nv + b.m);
+#define SPK_IB(TT, GG, UU, MPP) hipLaunchKernelGGL((iter_maxpy_uhead_kernel<TT, GG, UU, MPP>), dim3(grid), dim3(TT), 0, s, b)
+    const int mp = b.m == 0 ? 0 : (b.m <= 4 ? 4 : 8);
+    if (mp == 0) {
+        if (!thin) SPK_IB(512, 4, 4, 0);
+        else if (U == 2) SPK_IB(256, 8, 2, 0);
+        else SPK_IB(256, 8, 1, 0);
+    } else if (mp == 4) {
+        if (!thin) SPK_IB(512, 4, 4, 4);
+        else if (U == 2) SPK_IB(256, 8, 2, 4);
+        else SPK_IB(256, 8, 1, 4);
+    } else {
+        if (!thin) SPK_IB(512, 4, 4, 8);
+        else if (U == 2) SPK_IB(256, 8, 2, 8);
+        else SPK_IB(256, 8, 1, 8);
+    }
+#undef SPK_IB
 }
 
 // -ksp_gmres_cgs_refinement_type: mode 2 (always) refines unless done; mode 1 (ifneeded)

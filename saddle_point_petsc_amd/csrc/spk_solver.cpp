@@ -190,6 +190,8 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
             Ab.vbot.upload(vb.data(), vb.size(), 32);
             std::vector<int32_t> tb;
             k::build_btiles(brp.data(), Ab.nbrows, tb);
+            Ab.long_rows = false;
+            for (int32_t br = 0; br < Ab.nbrows && !Ab.long_rows; ++br) Ab.long_rows = brp[(size_t)br + 1] - brp[(size_t)br] > k::kBTile;
             Ab.ntiles = (int32_t)tb.size() - 1;
             Ab.tile_brow.upload(tb.data(), tb.size(), 8);
             Ab.ok = true;
@@ -658,6 +660,17 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const bool single = head && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                         o.single_reduce == 1 && mk + c->m <= k::kMaxNv - 1;
 
+    // two-launch iteration (spk_kernels.hip): same classical Gram-Schmidt with two reductions, MDot inside the
+    // SpMV launch, the next PC / B^T product inside the MAXPY launch.  Default below ~1 M rows, where launch
+    // boundaries and reduction tails outweigh the bytes; opts.iteration_form / SPK_ITER_FORM force either.
+    int form = o.iteration_form;
+    if (const char *e = getenv("SPK_ITER_FORM")) form = atoi(e);
+    const bool two_ok = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
+                        c->spmv_format == 1 && !c->Ab.long_rows && mk + c->m <= k::kMaxNv - 2;
+    const bool two = two_ok && (form == SPK_ITER_TWO_LAUNCH || (form == SPK_ITER_AUTO && nl < (1 << 20)));
+    if (two && !c->zun.p) c->zun.alloc((size_t)ld);
+    const int lam_in_dot = c->comm->rank() == 0 ? 1 : 0;
+
     c->ka.tentative = single ? 1 : 0;
     KrylovState st{};
     int32_t errword = 0;
@@ -667,7 +680,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
         else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
-        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, single ? c->ka.tb : nullptr, m);
+        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two) ? c->ka.tb : nullptr, m);
         if (!head) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
@@ -680,7 +693,71 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             const int32_t *done = &c->kst.p->skip_iter;  // the gate of everything inside an iteration
             double *w = Vj(loc + 1);
             double *db = dotsbuf(loc), *nb = nrmbuf(loc);
-            if (fused) {
+            if (two) {
+                k::SendRanges sr0 = c->send_ranges;
+                const bool packed = sr0.n > 0;
+                if (loc == 0) {
+                    // first iteration of a cycle: the classic head on the normalised r (no kernel B behind it)
+                    bool inhead = packed && c->comm->fused_halo(sr0, c->xghost.p);
+                    if (fused)
+                        k::fused_head(Vj(0), nrmbuf(1), w1side, c->dinv.p, bdp, ld, c->shat.p, c->gram.p, c->schur_fact, nl, m,
+                                      Zj(0), w, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr, bpk);
+                    else
+                        k::fused_head(Vj(0), nrmbuf(1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER, nl, 0,
+                                      Zj(0), nullptr, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr);
+                    prev_inhead = inhead;
+                }
+                // halo of the vector kernel A gathers (z~ of kernel B, or Z_0): the producer sent it (peer-store),
+                // or packed it (exchange here), or it is gathered first
+                const double *zsrc = loc == 0 ? Zj(0) : c->zun.p;
+                if (!c->peers.empty() && !prev_inhead) {
+                    if (!packed) k::gather(zsrc, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
+                    c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
+                }
+                k::IterA a{};
+                a.browptr = c->Ab.browptr.p; a.bcol = c->Ab.bcol.p; a.vtop = c->Ab.vtop.p; a.vbot = c->Ab.vbot.p;
+                a.tile_brow = c->Ab.tile_brow.p; a.ntiles = c->Ab.ntiles; a.tiles_per_xcd = (c->Ab.ntiles + 7) / 8;
+                a.slots = k::iter_slots(a.tiles_per_xcd);
+                a.od = c->n_ghost > 0 ? c->offdiag() : k::OffDiag{nullptr, nullptr, nullptr, nullptr};
+                a.zsrc = zsrc;
+                a.zdst = loc == 0 ? nullptr : Zj(loc);
+                a.vcur = Vj(loc);
+                a.w = w;
+                a.acc = fused ? 1 : 0;
+                a.nrm2 = loc == 0 ? nullptr : nrmbuf(loc - 1);
+                a.V = V; a.ldv = ld; a.nv = loc + 1;
+                a.bd = bdp; a.ldb = ld; a.m = m; a.packed = bpk;
+                a.nl = nl; a.lam_in_dot = lam_in_dot;
+                a.tb = c->ka.tb; a.wl_out = wl(0);
+                a.partials = c->partials.p; a.out = db;
+                a.ar = c->comm->fused_allreduce(loc + 1 + m, k::kStatArDots);
+                a.err = c->errw.p; a.fin_ticks = c->fin_ticks;
+                a.ka = c->ka; a.loc_prev = loc - 1; a.dots_prev = dotsbuf(loc - 1); a.nrm_prev = nrmbuf(loc - 1);
+                a.done = done;
+                k::iter_spmv_mdot(a, s);
+                if (!a.ar.P) c->comm->allreduce_sum(db, loc + 1 + m, s);
+                const k::PeerAR ar2 = c->comm->fused_allreduce(1, k::kStatArNorm);
+                if (loc + 1 < mk) {
+                    k::IterB b{};
+                    b.V = V; b.ldv = ld; b.nv = loc + 1; b.dots = db; b.tb = c->ka.tb;
+                    b.w = w; b.dinv = c->dinv.p; b.bd = bdp; b.ldb = ld; b.shat = c->shat.p; b.gram = c->gram.p;
+                    b.fact = fused ? c->schur_fact : SPK_SCHUR_LOWER;
+                    b.nl = nl; b.m = m; b.packed = bpk;
+                    b.zun = c->zun.p; b.c = fused ? Vj(loc + 2) : nullptr; b.wl_in = wl(0);
+                    b.lam_in_dot = lam_in_dot;
+                    b.partials = c->partials.p; b.out = nb; b.ar = ar2; b.err = c->errw.p; b.fin_ticks = c->fin_ticks;
+                    k::SendRanges sr = c->send_ranges;
+                    prev_inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
+                    if (sr.n > 0) b.sr = sr;
+                    b.done = done;
+                    k::iter_maxpy_uhead(b, s);
+                } else {
+                    // last iteration of the cycle: nothing follows the update but its norm
+                    k::maxpy(V, ld, loc + 1, nullptr, db, -1.0, w, N, n_dot, c->fin(nb, ar2), done, s);
+                }
+                if (!ar2.P) c->comm->allreduce_sum(nb, 1, s);
+                last = loc;  // its Givens step rides in kernel A of the next iteration (or runs alone below)
+            } else if (fused) {
                 // v_j = w'/||w'|| (in place), z_j = M^-1 v_j, w = B^T z1 (u part) | B z0 (lambda part);
                 // workgroup 0 also runs the Givens step of iteration loc-1
                 k::SendRanges sr = c->send_ranges;
@@ -716,7 +793,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
             }
-            if (o.orthog == SPK_ORTHOG_MGS) {
+            if (two) {
+                // (orthogonalisation done above, inside the two launches)
+            } else if (o.orthog == SPK_ORTHOG_MGS) {
                 // KSPGMRESModifiedGramSchmidtOrthogonalization: one dot + one axpy per basis vector
                 for (int j = 0; j <= loc; ++j) {
                     k::mdot(Vj(j), ld, 1, w, N, n_dot, c->fin(db + j), done, s);
