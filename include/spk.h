@@ -106,15 +106,16 @@ typedef struct spk_opts {
                                reductions otherwise). */
     int32_t iteration_form; /* how the head-kernel paths launch one classical Gram-Schmidt iteration (same
                                algorithm, two reductions, norms taken from w' itself):
-                               SPK_ITER_AUTO (0): two launches below ~1 M local rows, four above;
+                               SPK_ITER_AUTO (0): three launches below ~1 M local rows, four above;
                                SPK_ITER_FOUR_LAUNCH (1): head, SpMV, MDot, MAXPY;
                                SPK_ITER_TWO_LAUNCH (2): SpMV with MDot in its tile epilogues (VecScale of v and z
                                folded in), MAXPY with the norm and the next iteration's preconditioner + B^T
                                product on the un-normalised vector (B D w' by linearity from B D w).  Needs
-                               the 2x2-blocked matrix layout and restart + m <= 62; otherwise four launches. */
+                               the 2x2-blocked matrix layout and restart + m <= 62; otherwise four launches;
+                               SPK_ITER_THREE_LAUNCH (3): as 2 with VecMDot (h and B D w) as a launch of its own. */
     int32_t reserved;
 } spk_opts;
-enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2 };
+enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3 };
 
 typedef struct spk_result {
     int32_t its;            /* KSPGetIterationNumber   */

@@ -660,7 +660,16 @@ public:
     void check(hipStream_t s) override
     {
         (void)s;
-        if (error_word()) fail(SPK_ERR_COMM, "peer-store collective timed out after %u ms waiting for another rank", timeout_ms_);
+        if (error_word()) {
+            int32_t w[4] = {0, 0, 0, 0};
+            if (hipMemcpy(w, err_.p, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+            const char *where = w[1] == 1 ? "all-reduce after MDot" : w[1] == 2 ? "all-reduce after MAXPY" : w[1] == 3 ? "stand-alone all-reduce"
+                              : w[1] == 16 ? "halo rows (head kernel)" : w[1] == 17 ? "halo rows (MAXPY-head kernel)"
+                              : w[1] == 18 ? "halo rows (two-launch kernel B)" : w[1] == 19 ? "halo exchange kernel"
+                              : w[1] == 20 ? "bulk halo exchange kernel" : "unknown wait";
+            fail(SPK_ERR_COMM, "peer-store collective timed out after %u ms waiting for another rank (rank %d, first in: %s, sequence %d; "
+                               "all-reduces issued %u, halo exchanges issued %u)", timeout_ms_, me_, where, w[2], ar_seq_, halo_seq_);
+        }
     }
     void host_allgather(const void *in, void *out, size_t bytes_each) override { inner_->host_allgather(in, out, bytes_each); }
     void host_allgatherv(const void *in, size_t bytes_in, std::vector<std::vector<char>> &out) override

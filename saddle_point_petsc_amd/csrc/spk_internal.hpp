@@ -460,9 +460,10 @@ struct IterB {
     int gmain;           // set by the launcher
     const int32_t *done;
 };
-void iter_spmv_mdot(const IterA &a, hipStream_t s);
+// dots = false: the SpMV / normalisation part alone (three-launch form; one tile per workgroup: slots = tiles_per_xcd)
+void iter_spmv_mdot(const IterA &a, hipStream_t s, bool dots = true);
 void iter_maxpy_uhead(IterB b, hipStream_t s);
-int iter_slots(int tiles_per_xcd);
+int iter_slots(int tiles_per_xcd, int wg_per_cu);
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
 void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0);
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);

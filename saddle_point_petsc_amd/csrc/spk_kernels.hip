@@ -247,6 +247,18 @@ __device__ __forceinline__ bool granule_wait(const unsigned long long *p, uint32
     lo = (uint32_t)g;
     return true;
 }
+// Raises the sticky error word of the peer-store backend and notes WHICH wait gave up (first one wins):
+// err[1] = where (1..3: all-reduce after MDot / after MAXPY / stand-alone; 16: halo rows in a head kernel,
+// 17: in the MAXPY-head kernel, 18: in kernel B of the two-launch iteration, 19: granule exchange kernel,
+// 20: bulk exchange kernel), err[2] = sequence number waited for.
+__device__ __forceinline__ void raise_comm_error(int32_t *err, int where, uint32_t seq)
+{
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        err[1] = where;
+        err[2] = (int32_t)seq;
+    }
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ double join_halves(uint32_t lo, uint32_t hi)
 {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
@@ -280,7 +292,7 @@ __device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const doub
         atomicAdd(a.stats + 2 * a.kind + 1, 1ull);
     }
     if (!(t & 1)) out[t >> 1] = sum;
-    if (!ok) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) raise_comm_error(a.err, 1 + a.kind, a.seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -820,6 +832,95 @@ __global__ __launch_bounds__(256) void mdot_ws_kernel(const double *__restrict__
     else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
 }
 
+// Second form of the same turn (default; SPK_VEC_WS16=0 falls back to the one above): SIXTEEN waves per
+// workgroup, so a wave owns at most VW = 2..4 vectors and ALL its loads -- its tile of w and of each of
+// its vectors -- are issued before the first FMA: one memory round trip per tile where the four-wave
+// form walks its 8 vectors in 4 dependent rounds of two (measured on the 1/8 slab: 18.7 us for 30
+// vectors with four waves, the kernel is a chain of latencies, not of bytes).
+template <int VW, int U, bool NT>
+__global__ __launch_bounds__(1024) void mdot_ws16_kernel(const double *__restrict__ V, int64_t ldv, int nv,
+                                                         const double *__restrict__ V2, int nv1,
+                                                         const double *__restrict__ w, int64_t n2, int64_t n_dot,
+                                                         double *__restrict__ partials, int with_ww, double *__restrict__ out,
+                                                         PeerAR ar, int split, FinErr fe, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double lds[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (nv + 15) >> 4;
+    const int v0 = wave * per;
+    const int cnt = (nv - v0) < per ? (nv - v0) : per;  // may be <= 0: a wave without vectors
+    double acc[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) acc[i] = 0.0;
+    double ww = 0.0;
+    if (cnt > 0 || (wave == 0 && with_ww)) {
+        for (int64_t tile = blockIdx.x; tile * (64 * U) < n2; tile += gridDim.x) {
+            double2 wv[U], a[VW][U];
+            int64_t idx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idx[u] = tile * (64 * U) + u * 64 + lane;
+                if (idx[u] >= n2) idx[u] = -1;
+                wv[u] = ld2(w, idx[u] < 0 ? 0 : idx[u]);
+            }
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                const bool live = v < cnt;
+                const int ic = v0 + (live ? v : 0);
+                const int j2 = ic - nv1;  // split: "vector" j2 of the second slab is half j2 & 1 of plane j2 / 2
+                const double *Vi = !live ? w : (ic < nv1 ? V + (size_t)ic * ldv : V2 + (size_t)(split ? j2 >> 1 : j2) * ldv);
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, (live && idx[u] >= 0) ? idx[u] : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (idx[u] < 0 || 2 * idx[u] >= n_dot) wv[u].x = 0.0;
+                if (idx[u] < 0 || 2 * idx[u] + 1 >= n_dot) wv[u].y = 0.0;
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) ww += wv[u].x * wv[u].x + wv[u].y * wv[u].y;
+            }
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                const int ic = v0 + v;
+                double d = 0.0;
+                if (split && ic >= nv1 && v < cnt) {  // wave-uniform
+                    if ((ic - nv1) & 1) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) d += a[v][u].y * wv[u].y;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) d += a[v][u].x * wv[u].x + a[v][u].y * wv[u].y;
+                }
+                acc[v] += (v < cnt) ? d : 0.0;
+            }
+        }
+    }
+    double *row = partials + (size_t)blockIdx.x * kPartialLd;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        if (i < cnt) {  // wave-uniform
+            const double s = wave_sum(acc[i]);
+            if (lane == 0) publish(row + v0 + i, s);
+        }
+    }
+    if (wave == 0 && with_ww) {
+        const double s = wave_sum(ww);
+        if (lane == 0) publish(row + nv, s);
+    }
+    if (!arrive_last(gridDim.x)) return;
+    const int k = nv + (with_ww ? 1 : 0);
+    final_reduce(partials, gridDim.x, kPartialLd, k, lds, fe);
+    if (ar.P) peer_allreduce_block(ar, lds, k, out);
+    else if ((int)threadIdx.x < k) out[threadIdx.x] = lds[threadIdx.x];
+}
+
 // tile length (double2 per lane) and grid of the wave-split forms: about one tile per workgroup
 struct WsShape {
     int U, grid;
@@ -911,6 +1012,19 @@ void mdot(const double *V, int64_t ldv, int nv, const double *w, int64_t n, int6
         double *oo = f.out + v0;
         const int ng = (cnt + 7) / 8 > 0 ? (cnt + 7) / 8 : 1;
         const WsShape ws = ws_shape(n2);
+        static const int ws16 = [] { const char *e = getenv("SPK_VEC_WS16"); return e ? atoi(e) : 1; }();
+        if (ws.on && ws16) {
+            // sixteen waves, <= 3 vectors each (40 per launch), every load of a wave in flight at once
+#define SPK_MDOT_W16(VW, UU) hipLaunchKernelGGL((mdot_ws16_kernel<VW, UU, true>), dim3(ws.grid), dim3(1024), 0, s, Vp, ldv, cnt, V2p, \
+                                                nv1, w, n2, n_dot, pp, last, oo, f.ar, split, FinErr{f.err, f.fin_ticks}, done)
+            const int per = (cnt + 15) / 16;
+            if (ws.U == 8) { if (per <= 1) SPK_MDOT_W16(1, 8); else if (per <= 2) SPK_MDOT_W16(2, 8); else SPK_MDOT_W16(3, 4); }
+            else if (ws.U == 4) { if (per <= 1) SPK_MDOT_W16(1, 4); else if (per <= 2) SPK_MDOT_W16(2, 4); else SPK_MDOT_W16(3, 4); }
+            else { if (per <= 1) SPK_MDOT_W16(1, 2); else if (per <= 2) SPK_MDOT_W16(2, 2); else SPK_MDOT_W16(3, 2); }
+#undef SPK_MDOT_W16
+            v0 += 40;
+            continue;
+        }
         if (ws.on) {
 #define SPK_MDOT_WS(VW, UU, GG) hipLaunchKernelGGL((mdot_ws_kernel<VW, UU, GG, true>), dim3(ws.grid), dim3(256), 0, s, Vp, ldv, cnt, \
                                                    V2p, nv1, w, n2, n_dot, pp, last, oo, f.ar, split, FinErr{f.err, f.fin_ticks}, done)
@@ -1124,6 +1238,7 @@ void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const do
 {
     const int64_t n2 = (n + 1) / 2;
     const VecShape vs = vec_shape(n2, true);
+    static const int deep = [] { const char *e = getenv("SPK_VEC_DEEP"); return e ? atoi(e) : 0; }();
     PythArgs py{};
     py.m = -1;
     if (pyth) py = *pyth;
@@ -1132,8 +1247,14 @@ void maxpy(const double *V, int64_t ldv, int nv, const int32_t *nv_dev, const do
 #define SPK_MAXPY_ARGS mp, vs.grid, s, V, ldv, nv, nv_dev, a, coef_sign, w, n2, n_dot, f, bd, ldb, n_bd, m, w1side, py, packed, done
     if (vs.T == 512) maxpy_launch<512, 4, 4>(SPK_MAXPY_ARGS);
     else if (vs.U == 4) maxpy_launch<256, 4, 4>(SPK_MAXPY_ARGS);
+    // thin forms (small vectors), SPK_VEC_DEEP=1 only: the whole basis in ONE group of loads.  Measured SLOWER
+    // on the 1/8 slab (30 vectors: 13.2 us against 11.6 with groups of 8; 214 VGPRs leave two waves per SIMD):
+    // kept as a knob, off
+    else if (vs.U == 2 && vs.G == 8 && nv > 8 && deep) maxpy_launch<256, 2, 16>(SPK_MAXPY_ARGS);
     else if (vs.U == 2 && vs.G == 8) maxpy_launch<256, 2, 8>(SPK_MAXPY_ARGS);
     else if (vs.U == 2) maxpy_launch<256, 2, 4>(SPK_MAXPY_ARGS);
+    else if (vs.G == 8 && nv > 16 && deep) maxpy_launch<256, 1, 32>(SPK_MAXPY_ARGS);
+    else if (vs.G == 8 && nv > 8 && deep) maxpy_launch<256, 1, 16>(SPK_MAXPY_ARGS);
     else if (vs.G == 8) maxpy_launch<256, 1, 8>(SPK_MAXPY_ARGS);
     else maxpy_launch<256, 1, 4>(SPK_MAXPY_ARGS);
 #undef SPK_MAXPY_ARGS
@@ -1286,7 +1407,7 @@ __global__ __launch_bounds__(kThreads) void peer_exchange_kernel(PeerHalo h, con
         }
         const uint32_t other = __shfl_xor(lo, 1, kWave);
         if (!(g & 1)) recvbuf[g >> 1] = join_halves(lo, other);
-        if (!ok) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) raise_comm_error(h.err, 19, h.seq);
     }
 }
 void peer_exchange(const PeerHalo &h, const double *sendbuf, double *recvbuf, hipStream_t s)
@@ -1345,7 +1466,7 @@ __global__ __launch_bounds__(kThreads) void peer_exchange_bulk_kernel(PeerBulk h
             atomicAdd(h.stats + 2 * kStatHalo, wall_clock64() - tw0);
             atomicAdd(h.stats + 2 * kStatHalo + 1, 1ull);
         }
-        if (!ok) __hip_atomic_store(h.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) raise_comm_error(h.err, 20, h.seq);
         okf = ok;
     }
     __syncthreads();
@@ -1845,7 +1966,11 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t 
 // loads), lane 0 runs the dependent chain out of LDS and writes the column back once.
 // Called from the stand-alone kernel (generic path) and from workgroup 0 of the fused
 // iteration-head kernel, where it overlaps with that kernel's streaming.
-__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2)
+// gate != nullptr (two words in LDS, zeroed by the caller): the words that GATE the kernels of an
+// iteration (done, skip_iter) are not stored here but handed back as gate[0], gate[1]; the caller
+// stores them once no workgroup of ITS launch can still be about to read them (kernel A of the
+// two-launch iteration: its workgroups must all take the same branch, they feed one reduction).
+__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate = nullptr)
 {
     __shared__ double Hc[kMaxNv + 2], Hr[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
     KrylovState *st = ka.st;
@@ -1867,8 +1992,8 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
     if (isnan(tt) || isinf(tt)) {  // KSPCheckNorm: KSP_DIVERGED_NANORINF
         st->rnorm = tt;
         st->reason = SPK_DIVERGED_NANORINF;
-        st->done = 1;
-        st->skip_iter = 1;
+        if (gate) gate[0] = gate[1] = 1;
+        else st->done = 1, st->skip_iter = 1;
         return;
     }
     // happy breakdown test
@@ -1896,8 +2021,8 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
         const double d = sqrt(h0 * h0 + h1 * h1);
         if (d == 0.0) {
             st->reason = SPK_DIVERGED_NULL;
-            st->done = 1;
-            st->skip_iter = 1;
+            if (gate) gate[0] = gate[1] = 1;
+            else st->done = 1, st->skip_iter = 1;
             return;
         }
         const double c = h0 / d, sn = h1 / d;
@@ -1922,13 +2047,14 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
     if (reason > 0 && ka.tentative) {
         // single-reduction mode: ||w'|| came out of a difference that can sit in rounding noise, so the
         // recurrence is trusted to END THE CYCLE only; the restart's true residual decides (krylov_cycle_begin)
-        st->skip_iter = 1;
+        if (gate) gate[1] = 1;
+        else st->skip_iter = 1;
         return;
     }
     st->reason = reason;
     if (reason) {
-        st->done = 1;
-        st->skip_iter = 1;
+        if (gate) gate[0] = gate[1] = 1;
+        else st->done = 1, st->skip_iter = 1;
     }
 }
 
@@ -2017,7 +2143,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
             }
             const uint32_t other = __shfl_xor(lo, 1, kWave);
             if (!(g & 1)) sr.xghost[g >> 1] = join_halves(lo, other);
-            if (!ok) __hip_atomic_store(sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) raise_comm_error(sr.err, 16, sr.seq);
         }
         return;
     }
@@ -2211,7 +2337,7 @@ __global__ __launch_bounds__(T) void maxpy_head_kernel(
             }
             const uint32_t other = __shfl_xor(lo, 1, kWave);
             if (!(g & 1)) sr.xghost[g >> 1] = join_halves(lo, other);
-            if (!ok) __hip_atomic_store(sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) raise_comm_error(sr.err, 17, sr.seq);
         }
         return;
     }
@@ -2379,8 +2505,8 @@ __device__ __forceinline__ double inv_norm(double nrm2)
     return tt > 1e-300 ? 1.0 / tt : 1.0;
 }
 
-template <int VW>
-__global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
+template <int VW, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
 {
     if (*a.done) return;
     __shared__ double prod[kBTile * 4];
@@ -2388,7 +2514,11 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
     const double scale = a.nrm2 ? inv_norm(a.nrm2[0]) : 1.0;
     const int nmain = 8 * a.slots;
     const int nv = a.nv, m = a.m;
-    if ((int)blockIdx.x == nmain) {
+    // the scalar workgroup: LAST where it is also the reducer (it has to wait for the others anyway), FIRST in the
+    // three-launch form -- its Givens chain then runs beside the streaming instead of behind it
+    const int scalar_wg = VW > 0 ? nmain : 0;
+    const int bid = VW > 0 ? (int)blockIdx.x : (int)blockIdx.x - 1;
+    if ((int)blockIdx.x == scalar_wg) {
         // ---- the scalar / reducing workgroup
         double *lamw = wt;
         if ((int)threadIdx.x < m) {
@@ -2406,19 +2536,31 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
             a.wl_out[r] = wl;
             lamw[r] = wl;
         }
+        __shared__ int gate[2];
+        if (threadIdx.x < 2) gate[threadIdx.x] = 0;
         __syncthreads();
-        if (a.loc_prev >= 0) givens_block(a.ka, a.loc_prev, a.dots_prev, a.nrm_prev);
+        // Givens step of the previous iteration, while the others stream.  Its verdict (done / skip_iter) is
+        // stored only at the very end: every workgroup of this launch has long passed its own look at `done`
+        // by then -- they feed one reduction and must all take the same branch (under load the XCDs start
+        // their workgroups at different times).
+        if (a.loc_prev >= 0) givens_block(a.ka, a.loc_prev, a.dots_prev, a.nrm_prev, gate);
         __syncthreads();
-        const int k = nv + m;
-        final_reduce(a.partials, nmain, kPartialLd, k, prod, FinErr{a.err, a.fin_ticks});
-        if (a.lam_in_dot && (int)threadIdx.x < nv) {  // multiplier entries of the inner products (rank 0 only)
-            double sl = 0.0;
-            for (int r = 0; r < m; ++r) sl += a.V[(size_t)threadIdx.x * a.ldv + a.nl + r] * lamw[r];
-            prod[threadIdx.x] += sl;
+        if (VW > 0) {  // VW == 0: the three-launch form, VecMDot is a launch of its own
+            const int k = nv + m;
+            final_reduce(a.partials, nmain, kPartialLd, k, prod, FinErr{a.err, a.fin_ticks});
+            if (a.lam_in_dot && (int)threadIdx.x < nv) {  // multiplier entries of the inner products (rank 0 only)
+                double sl = 0.0;
+                for (int r = 0; r < m; ++r) sl += a.V[(size_t)threadIdx.x * a.ldv + a.nl + r] * lamw[r];
+                prod[threadIdx.x] += sl;
+            }
+            __syncthreads();
+            if (a.ar.P) peer_allreduce_block(a.ar, prod, k, a.out);
+            else if ((int)threadIdx.x < k) a.out[threadIdx.x] = prod[threadIdx.x];
         }
-        __syncthreads();
-        if (a.ar.P) peer_allreduce_block(a.ar, prod, k, a.out);
-        else if ((int)threadIdx.x < k) a.out[threadIdx.x] = prod[threadIdx.x];
+        if (threadIdx.x == 0) {  // every partial has arrived: no workgroup of this launch reads the gate any more
+            if (gate[0]) a.ka.st->done = 1;
+            if (gate[1]) a.ka.st->skip_iter = 1;
+        }
         return;
     }
 
@@ -2428,18 +2570,25 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
     const int per = (nvt + 3) >> 2;
     const int v0 = wave * per;
     const int cnt = (nvt - v0) < per ? (nvt - v0) : per;  // <= 0: a wave without vectors
-    double acc[VW];
+    double acc[VW > 0 ? VW : 1];
 #pragma unroll
-    for (int i = 0; i < VW; ++i) acc[i] = 0.0;
+    for (int i = 0; i < (VW > 0 ? VW : 1); ++i) acc[i] = 0.0;
 
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     for (int tl = slot; tl < a.tiles_per_xcd; tl += a.slots) {
         const int t = xcd * a.tiles_per_xcd + tl;
         if (t >= a.ntiles) break;
         const int br0 = a.tile_brow[t], br1 = a.tile_brow[t + 1];
         const int b0 = a.browptr[br0], b1 = a.browptr[br1];
         const int cntb = b1 - b0;
-        // phase 1: the tile's matrix stream, x gathered 16 bytes at a time (as spmv_bcsr_kernel)
+        const int nr = 2 * (br1 - br0), r0 = 2 * br0;
+        const int lr = threadIdx.x;
+        // ---- every load that depends on nothing computed in this tile is issued FIRST: the matrix stream, the
+        // row thread's own operands, and the rows of the basis vectors the dot phase will need (they do not
+        // depend on w).  The tile then costs two memory round trips (these, and the gather of x behind the
+        // block columns) instead of one per phase -- with <= 4 workgroups per CU the phases of a tile are a
+        // chain of latencies, not of bytes (first version: 27-38 us on the 1/8 slab against 10 + 12 for
+        // SpMV and MDot as launches of their own).
         constexpr int kSteps = kBTile / kThreads;
         int c[kSteps];
         double2 tp[kSteps], bo[kSteps];
@@ -2452,6 +2601,38 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
                 bo[i] = ld2s<true>(a.vbot, b0 + q);
             }
         }
+        double wpre = 0.0, vrow = 0.0, zrow = 0.0;
+        int k0 = 0, k1 = 0, o0 = 0, o1 = 0;
+        if (lr < nr) {
+            const int br = br0 + (lr >> 1), r = r0 + lr;
+            k0 = a.browptr[br] - b0;
+            k1 = a.browptr[br + 1] - b0;
+            if (a.acc) wpre = a.w[r];
+            if (a.nrm2) {
+                vrow = a.vcur[r];
+                zrow = a.zsrc[r];
+            }
+            if (a.od.rowptr) {
+                o0 = a.od.rowptr[r];
+                o1 = a.od.rowptr[r + 1];
+            }
+        }
+        constexpr int RL = 2;  // rows per lane whose basis entries are fetched ahead (tiles of <= 128 rows: all of them)
+        double av[VW > 0 ? VW : 1][RL];
+        if (VW > 0) {
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                const int i = v0 + v;
+                const bool live = v < cnt && !(a.nrm2 && i == nv - 1);  // the vector normalised here comes from LDS
+                const double *src = i < nv ? a.V + (size_t)i * a.ldv : a.bd + (size_t)(i - nv) * a.ldb;
+#pragma unroll
+                for (int j = 0; j < RL; ++j) {
+                    const int k = lane + 64 * j;
+                    av[v][j] = (live && k < nr) ? ld1nt(src + r0 + k) : 0.0;
+                }
+            }
+        }
+        // phase 1: gather x 16 bytes at a time behind the block columns, products to LDS
 #pragma unroll
         for (int i = 0; i < kSteps; ++i) {
             const int q = i * kThreads + threadIdx.x;
@@ -2468,11 +2649,8 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
         }
         __syncthreads();
         // phase 2: one thread per row, CSR order; scaling and normalisation of the row's entries
-        const int nr = 2 * (br1 - br0), r0 = 2 * br0;
-        const int lr = threadIdx.x;
         if (lr < nr) {
-            const int br = br0 + (lr >> 1), half = lr & 1;
-            const int k0 = a.browptr[br] - b0, k1 = a.browptr[br + 1] - b0;
+            const int half = lr & 1;
             double sr = 0.0;
             for (int k = k0; k < k1; ++k) {
                 const double2 p = *reinterpret_cast<const double2 *>(prod + 4 * k + 2 * half);
@@ -2480,56 +2658,51 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
                 sr += p.y;
             }
             const int r = r0 + lr;
-            if (a.od.rowptr)
-                for (int k = a.od.rowptr[r]; k < a.od.rowptr[r + 1]; ++k) sr += a.od.val[k] * a.od.xg[a.od.colidx[k]];
-            if (a.acc) sr += a.w[r];
+            for (int k = o0; k < o1; ++k) sr += a.od.val[k] * a.od.xg[a.od.colidx[k]];
+            if (a.acc) sr += wpre;
             const double wv = sr * scale;
             a.w[r] = wv;
             wt[lr] = wv;
             if (a.nrm2) {
-                const double vn = a.vcur[r] * scale;
+                const double vn = vrow * scale;
                 a.vcur[r] = vn;
                 vt[lr] = vn;
-                a.zdst[r] = a.zsrc[r] * scale;
+                a.zdst[r] = zrow * scale;
             }
         }
-        __syncthreads();
+        __syncthreads();  // phase 2 has read prod; wt / vt are complete
+        if (VW == 0) continue;  // three-launch form: VecMDot is a launch of its own
         // phase 3: this tile's share of V^T w and B D w; the waves split the VECTORS, lane k owns rows k, k+64, ..
         if (cnt > 0) {
             double wr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) wr[j] = (lane + 64 * j) < nr ? wt[lane + 64 * j] : 0.0;
-            constexpr int G = 4;
 #pragma unroll
-            for (int g0 = 0; g0 < VW; g0 += G) {
-                if (g0 < cnt) {  // wave-uniform
-                    double av[G][4];
+            for (int v = 0; v < VW; ++v) {
+                const int i = v0 + v;
+                if (v < cnt) {  // wave-uniform
+                    if (a.nrm2 && i == nv - 1) {
 #pragma unroll
-                    for (int v = 0; v < G; ++v) {
-                        const int i = v0 + g0 + v;
-                        const bool live = g0 + v < cnt;
-                        const bool fromlds = a.nrm2 && i == nv - 1;  // the vector this launch normalises: its rows are in LDS
-                        const double *src = i < nv ? a.V + (size_t)i * a.ldv : a.bd + (size_t)(i - nv) * a.ldb;
+                        for (int j = 0; j < 4; ++j)
+                            if (64 * j < nr && lane + 64 * j < nr) acc[v] += vt[lane + 64 * j] * wr[j];
+                    } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            av[v][j] = 0.0;
-                            if (64 * j < nr) {  // wave-uniform
-                                const int k = lane + 64 * j;
-                                if (live && k < nr) av[v][j] = fromlds ? vt[k] : ld1nt(src + r0 + k);
-                            }
+                        for (int j = 0; j < RL; ++j) acc[v] += av[v][j] * wr[j];
+                        if (nr > 64 * RL) {  // tiles beyond 128 rows (not the grids' 112): the remaining rows, fetched late
+                            const double *src = i < nv ? a.V + (size_t)i * a.ldv : a.bd + (size_t)(i - nv) * a.ldb;
+#pragma unroll
+                            for (int j = RL; j < 4; ++j)
+                                if (lane + 64 * j < nr) acc[v] += ld1nt(src + r0 + lane + 64 * j) * wr[j];
                         }
                     }
-#pragma unroll
-                    for (int v = 0; v < G; ++v)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[g0 + v] += av[v][j] * wr[j];
                 }
             }
         }
         __syncthreads();  // prod / wt / vt are reused by the next tile
     }
+    if (VW == 0) return;
     // this workgroup's partial sums: value i of [h_0..h_{nv-1}, q_0..q_{m-1}] comes from exactly one wave
-    double *row = a.partials + (size_t)blockIdx.x * kPartialLd;
+    double *row = a.partials + (size_t)bid * kPartialLd;
 #pragma unroll
     for (int il = 0; il < VW; ++il) {
         if (il < cnt) {  // wave-uniform
@@ -2550,27 +2723,34 @@ __global__ __launch_bounds__(kThreads) void iter_spmv_mdot_kernel(IterA a)
     }
 }
 
-void iter_spmv_mdot(const IterA &a, hipStream_t s)
-{
-    const int np = a.packed ? a.m / 2 : a.m;
-    const int per = (a.nv + np + 3) / 4;
-    const dim3 grid(8 * a.slots + 1), block(kThreads);
-    if (a.nv + a.m > kMaxNv - 1) fail(SPK_ERR_ARG, "iter_spmv_mdot: %d values exceed one reduction", a.nv + a.m);
-    if (per <= 4) hipLaunchKernelGGL(iter_spmv_mdot_kernel<4>, grid, block, 0, s, a);
-    else if (per <= 8) hipLaunchKernelGGL(iter_spmv_mdot_kernel<8>, grid, block, 0, s, a);
-    else if (per <= 12) hipLaunchKernelGGL(iter_spmv_mdot_kernel<12>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(iter_spmv_mdot_kernel<16>, grid, block, 0, s, a);
-}
-
 // Workgroups a launch of kernel A runs per XCD: every slot gets the same number of tiles (+-1), all of
-// them co-resident (<= 4 workgroups of 256 threads per CU are assumed: the kernel holds up to 16
-// accumulators and 16 loads in flight per lane next to the SpMV's own registers)
-int iter_slots(int tiles_per_xcd)
+// them co-resident (wg_per_cu workgroups of 256 threads per CU: what the instantiation's registers allow)
+int iter_slots(int tiles_per_xcd, int wg_per_cu)
 {
-    const int smax = 32 * 4;  // CUs per XCD x workgroups per CU
+    const int smax = 32 * wg_per_cu;  // CUs per XCD x workgroups per CU
     if (tiles_per_xcd <= smax) return tiles_per_xcd > 0 ? tiles_per_xcd : 1;
     const int tpw = (tiles_per_xcd + smax - 1) / smax;
     return (tiles_per_xcd + tpw - 1) / tpw;
+}
+
+void iter_spmv_mdot(const IterA &a0, hipStream_t s, bool dots)
+{
+    IterA a = a0;
+    const int np = a.packed ? a.m / 2 : a.m;
+    const int per = (a.nv + np + 3) / 4;
+    if (a.nv + a.m > kMaxNv - 1) fail(SPK_ERR_ARG, "iter_spmv_mdot: %d values exceed one reduction", a.nv + a.m);
+    static const int occ8 = [] { const char *e = getenv("SPK_ITERA_OCC"); return e ? atoi(e) : 4; }();
+    // workgroups per XCD: one tile each without the dot phase; with it, as many as are co-resident (the
+    // accumulators live across a workgroup's tiles), every slot the same number of tiles (+-1)
+    const int occ = !dots ? 0 : (per <= 4 ? 4 : (per <= 8 ? (occ8 == 4 ? 4 : 3) : 2));
+    a.slots = !dots ? (a.tiles_per_xcd > 0 ? a.tiles_per_xcd : 1) : iter_slots(a.tiles_per_xcd, occ);
+    const dim3 grid(8 * a.slots + 1), block(kThreads);
+    if (!dots) hipLaunchKernelGGL((iter_spmv_mdot_kernel<0, 4>), grid, block, 0, s, a);
+    else if (per <= 4) hipLaunchKernelGGL((iter_spmv_mdot_kernel<4, 4>), grid, block, 0, s, a);
+    else if (per <= 8 && occ8 == 4) hipLaunchKernelGGL((iter_spmv_mdot_kernel<8, 4>), grid, block, 0, s, a);
+    else if (per <= 8) hipLaunchKernelGGL((iter_spmv_mdot_kernel<8, 3>), grid, block, 0, s, a);
+    else if (per <= 12) hipLaunchKernelGGL((iter_spmv_mdot_kernel<12, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((iter_spmv_mdot_kernel<16, 2>), grid, block, 0, s, a);
 }
 
 template <int T, int G, int U, int MP>
@@ -2580,39 +2760,100 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
     __shared__ double hs[kMaxNv], lam[kMaxNv * 8], ys[8], wraws[8], tus[8];
     __shared__ double red[T];
     const int nv = b.nv, m = b.m;
-    // ---- scalars, derived by every workgroup from the reduced [h, q] ----
+    constexpr int NP = MP > 0 ? MP : 1;
+    const int gmain = b.gmain;
+    const int nhalo = b.sr.peer ? (2 * b.sr.nrecv + T - 1) / T : 0;
+    const bool is_main = (int)blockIdx.x < gmain;
+    const int64_t n2 = b.nl / 2;
+    const int bid = blockIdx.x;
+    // with a halo to send the grid is walked from both ends inwards (the rows the neighbours wait for leave first)
+    const int bx = b.sr.peer ? ((bid & 1) ? gmain - 1 - (bid >> 1) : (bid >> 1)) : bid;
+
+    // ---- a streaming workgroup puts the loads of its first tile in flight BEFORE the scalar prologue: w, D, the
+    // planes of B D and the first group of basis vectors depend on none of it, and the prologue is a chain of two
+    // memory round trips of its own (kernel of 16 us on the 1/8 slab, 8 us of them not bytes)
+    constexpr bool PRE = U * (MP > 0 ? MP : 1) <= 16;  // planes of B D fetched ahead too, where the registers allow (not 512 x 4 x 8 rows)
+    double2 wv[U], dv[U], pe[PRE ? NP : 1][U], t0[G][U];
+    int64_t idx[U];
+    bool ok[U];
+    int64_t tile = bx;
+    auto load_planes = [&]() {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const bool live = b.packed ? 2 * q < m : q < m;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pe[q][u].x = pe[q][u].y = 0.0;
+                if (live) pe[q][u] = ld2s<true>(b.bd + (size_t)q * b.ldb, idx[u]);
+            }
+        }
+    };
+    auto load_tile = [&](int64_t tl) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            idx[u] = tl * (T * U) + u * T + threadIdx.x;
+            ok[u] = idx[u] < n2;
+            if (!ok[u]) idx[u] = 0;
+            wv[u] = ld2(b.w, idx[u]);
+            dv[u] = ld2(b.dinv, idx[u]);
+        }
+        if (MP > 0 && PRE) load_planes();
+#pragma unroll
+        for (int v = 0; v < G; ++v) {
+            const bool live = v < nv;
+            const double *Vi = b.V + (size_t)(live ? v : 0) * b.ldv;
+#pragma unroll
+            for (int u = 0; u < U; ++u) t0[v][u] = ld2s<true>(Vi, live ? idx[u] : 0);
+        }
+    };
+    bool have = is_main && tile * (T * U) < n2;
+    if (have) load_tile(tile);
+
+    // ---- scalars, derived by every workgroup from the reduced [h, q]; all their loads first
+    double lamv = 0.0;
+    const bool lam_mine = (int)threadIdx.x < nv * m;
+    if (lam_mine) lamv = b.V[(size_t)(threadIdx.x / m) * b.ldv + b.nl + (threadIdx.x % m)];
+    double wl = 0.0, sh = 1.0;
+    if ((int)threadIdx.x < m) {
+        wl = b.wl_in[threadIdx.x];
+        sh = b.shat[threadIdx.x];
+    }
     if (threadIdx.x < kWave) {  // lane i owns basis vector i (nv <= 63)
         const int i = threadIdx.x;
         const double hi = i < nv ? b.dots[i] : 0.0;
+        double tbv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tbv[r] = (r < m && i < nv) ? b.tb[i * 8 + r] : 0.0;
+        const double qv = (i < m) ? b.dots[nv + i] : 0.0;
         if (i < nv) hs[i] = hi;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (r < m) {  // uniform
-                const double tsum = wave_sum(i < nv ? hi * b.tb[i * 8 + r] : 0.0);
-                if (i == 0) tus[r] = b.dots[nv + r] - tsum;  // B D w' = B D w - sum h_i (B D v_i)
+                const double tsum = wave_sum(hi * tbv[r]);
+                const double qr = __shfl(qv, r, kWave);
+                if (i == 0) tus[r] = qr - tsum;  // B D w' = B D w - sum h_i (B D v_i)
             }
         }
     }
-    for (int t = threadIdx.x; t < nv * m; t += T) lam[t] = b.V[(size_t)(t / m) * b.ldv + b.nl + (t % m)];
+    if (lam_mine) lam[threadIdx.x] = lamv;
+    for (int t = threadIdx.x + T; t < nv * m; t += T) lam[t] = b.V[(size_t)(t / m) * b.ldv + b.nl + (t % m)];
     __syncthreads();
-    if ((int)threadIdx.x < MP) {
+    if ((int)threadIdx.x < NP && MP > 0) {
         const int r = threadIdx.x;
         double y = 0.0, wraw = 0.0;
         if (r < m) {
-            wraw = b.wl_in[r];
+            wraw = wl;
             for (int i = 0; i < nv; ++i) wraw += -hs[i] * lam[i * m + r];  // the MAXPY of the multiplier entries
-            y = -(wraw - tus[r]) / b.shat[r];
+            y = -(wraw - tus[r]) / sh;
         }
         wraws[r] = wraw;
         ys[r] = y;
     }
     __syncthreads();
-    double yv[MP > 0 ? MP : 1];
+    double yv[NP];
 #pragma unroll
-    for (int r = 0; r < (MP > 0 ? MP : 1); ++r) yv[r] = MP > 0 ? ys[r] : 0.0;
+    for (int r = 0; r < NP; ++r) yv[r] = MP > 0 ? ys[r] : 0.0;
 
-    const int gmain = b.gmain;
-    const int nhalo = b.sr.peer ? (2 * b.sr.nrecv + T - 1) / T : 0;
     if ((int)blockIdx.x == gmain + nhalo) {
         // ---- the scalar / reducing workgroup: multiplier entries of w', z~, c~; B D w' for the recurrence
         if ((int)threadIdx.x < m) {
@@ -2625,7 +2866,6 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
             b.c[b.nl + r] = w1;
             b.tb[(size_t)nv * 8 + r] = tus[r];  // un-normalised; kernel A of the next iteration scales it
         }
-        red[threadIdx.x] = 0.0;
         __syncthreads();
         final_reduce(b.partials, gmain, kPartialLd, 1, red, FinErr{b.err, b.fin_ticks});
         if (threadIdx.x == 0) {
@@ -2638,67 +2878,77 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         else if (threadIdx.x == 0) b.out[0] = red[0];
         return;
     }
-    const int64_t n2 = b.nl / 2;
-    if ((int)blockIdx.x >= gmain) {  // peer-store halo: unpack this rank's ghost rows (see fused_head_kernel)
+    if (!is_main) {  // peer-store halo: unpack this rank's ghost rows (see fused_head_kernel)
         const int64_t g = (int64_t)((int)blockIdx.x - gmain) * T + threadIdx.x;
         if (g < 2 * (int64_t)b.sr.nrecv) {
             uint32_t lo;
             const unsigned long long tw0 = (b.sr.stats && threadIdx.x == 0) ? wall_clock64() : 0ull;
-            const bool ok = granule_wait(b.sr.mine + g, b.sr.seq, b.sr.timeout_ms, lo, b.sr.err, b.done);
+            const bool okw = granule_wait(b.sr.mine + g, b.sr.seq, b.sr.timeout_ms, lo, b.sr.err, b.done);
             if (b.sr.stats && threadIdx.x == 0) {
                 atomicAdd(b.sr.stats + 2 * kStatHalo, wall_clock64() - tw0);
                 atomicAdd(b.sr.stats + 2 * kStatHalo + 1, 1ull);
             }
             const uint32_t other = __shfl_xor(lo, 1, kWave);
             if (!(g & 1)) b.sr.xghost[g >> 1] = join_halves(lo, other);
-            if (!ok) __hip_atomic_store(b.sr.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!okw) raise_comm_error(b.sr.err, 18, b.sr.seq);
         }
         return;
     }
-    const int bid = blockIdx.x;
-    const int bx = b.sr.peer ? ((bid & 1) ? gmain - 1 - (bid >> 1) : (bid >> 1)) : bid;
     double nrm = 0.0;
-    for (int64_t tile = bx; tile * (T * U) < n2; tile += gmain) {
-        double2 wv[U], dv[U], sv[U];
-        int64_t idx[U];
-        bool ok[U];
+    while (have) {
+        double2 sv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            idx[u] = tile * (T * U) + u * T + threadIdx.x;
-            ok[u] = idx[u] < n2;
-            if (!ok[u]) idx[u] = 0;
-            wv[u] = ld2(b.w, idx[u]);
-            dv[u] = ld2(b.dinv, idx[u]);
-            sv[u].x = sv[u].y = 0.0;
-        }
-        if (MP > 0) {
-            if (b.packed) {
+        for (int u = 0; u < U; ++u) sv[u].x = sv[u].y = 0.0;
+        if (MP > 0 && !PRE) {  // fat workgroups with many rows: one plane at a time
 #pragma unroll
-                for (int q = 0; q < MP / 2; ++q) {
-                    if (2 * q < m) {
+            for (int q = 0; q < NP; ++q) {
+                const bool live = b.packed ? 2 * q < m : q < m;
+                if (live) {
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const double2 e = ld2s<true>(b.bd + (size_t)q * b.ldb, idx[u]);
+                    for (int u = 0; u < U; ++u) {
+                        const double2 e = ld2s<true>(b.bd + (size_t)q * b.ldb, idx[u]);
+                        if (b.packed) {
                             sv[u].x += e.x * yv[2 * q];
                             sv[u].y += e.y * yv[2 * q + 1];
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < MP; ++r) {
-                    if (r < m) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const double2 e = ld2s<true>(b.bd + (size_t)r * b.ldb, idx[u]);
-                            sv[u].x += e.x * yv[r];
-                            sv[u].y += e.y * yv[r];
+                        } else {
+                            sv[u].x += e.x * yv[q];
+                            sv[u].y += e.y * yv[q];
                         }
                     }
                 }
             }
+        } else if (MP > 0) {
+            if (b.packed) {
+#pragma unroll
+                for (int q = 0; q < NP / 2; ++q) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        sv[u].x += pe[q][u].x * yv[2 * q];
+                        sv[u].y += pe[q][u].y * yv[2 * q + 1];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        sv[u].x += pe[r][u].x * yv[r];
+                        sv[u].y += pe[r][u].y * yv[r];
+                    }
+                }
+            }
         }
-        for (int g0 = 0; g0 < nv; g0 += G) {
+        // first group of basis vectors: already here
+#pragma unroll
+        for (int v = 0; v < G; ++v) {
+            const double ai = v < nv ? -hs[v] : 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                wv[u].x += ai * t0[v][u].x;
+                wv[u].y += ai * t0[v][u].y;
+            }
+        }
+        for (int g0 = G; g0 < nv; g0 += G) {
             double2 t[G][U];
             double ai[G];
 #pragma unroll
@@ -2760,8 +3010,13 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
                 }
             }
         }
+        tile += gmain;
+        have = tile * (T * U) < n2;
+        if (have) load_tile(tile);
     }
-    // ||w'||^2 of this workgroup's entries
+    // ||w'||^2 of this workgroup's entries.  The partial goes to slot bx -- the FIRST TILE this workgroup
+    // streamed -- so that the reducer adds the partials in tile order whichever way the grid was walked
+    // (bit-identical norms with and without the peer-store halo in the same launch)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double sw = wave_sum(nrm);
     if (lane == 0) red[wave] = sw;
@@ -2770,7 +3025,7 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         double tsum = 0.0;
 #pragma unroll
         for (int j = 0; j < T / kWave; ++j) tsum += red[j];
-        publish(b.partials + (size_t)blockIdx.x * kPartialLd, tsum);
+        publish(b.partials + (size_t)bx * kPartialLd, tsum);
     }
 }
 
@@ -2788,19 +3043,21 @@ void iter_maxpy_uhead(IterB b, hipStream_t s)
     if (b.nv + b.m > kMaxNv - 1) fail(SPK_ERR_ARG, "iter_maxpy_uhead: %d values exceed one reduction", b.nv + b.m);
 #define SPK_IB(TT, GG, UU, MPP) hipLaunchKernelGGL((iter_maxpy_uhead_kernel<TT, GG, UU, MPP>), dim3(grid), dim3(TT), 0, s, b)
     const int mp = b.m == 0 ? 0 : (b.m <= 4 ? 4 : 8);
-    if (mp == 0) {
-        if (!thin) SPK_IB(512, 4, 4, 0);
-        else if (U == 2) SPK_IB(256, 8, 2, 0);
-        else SPK_IB(256, 8, 1, 0);
-    } else if (mp == 4) {
-        if (!thin) SPK_IB(512, 4, 4, 4);
-        else if (U == 2) SPK_IB(256, 8, 2, 4);
-        else SPK_IB(256, 8, 1, 4);
-    } else {
-        if (!thin) SPK_IB(512, 4, 4, 8);
-        else if (U == 2) SPK_IB(256, 8, 2, 8);
-        else SPK_IB(256, 8, 1, 8);
-    }
+    static const int deep = [] { const char *e = getenv("SPK_VEC_DEEP"); return e ? atoi(e) : 0; }();
+    // thin forms: the whole basis in one group of loads where registers allow (see maxpy)
+    const int g1 = !deep || b.nv <= 8 ? 8 : (b.nv <= 16 ? 16 : 32), g2 = !deep || b.nv <= 8 ? 8 : 16;
+#define SPK_IB_MP(MPP)                                                           \
+    do {                                                                         \
+        if (!thin) SPK_IB(512, 4, 4, MPP);                                       \
+        else if (U == 2) { if (g2 == 16) SPK_IB(256, 16, 2, MPP); else SPK_IB(256, 8, 2, MPP); } \
+        else if (g1 == 32) SPK_IB(256, 32, 1, MPP);                              \
+        else if (g1 == 16) SPK_IB(256, 16, 1, MPP);                              \
+        else SPK_IB(256, 8, 1, MPP);                                             \
+    } while (0)
+    if (mp == 0) SPK_IB_MP(0);
+    else if (mp == 4) SPK_IB_MP(4);
+    else SPK_IB_MP(8);
+#undef SPK_IB_MP
 #undef SPK_IB
 }
 

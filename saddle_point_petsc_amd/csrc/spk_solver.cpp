@@ -667,7 +667,13 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     if (const char *e = getenv("SPK_ITER_FORM")) form = atoi(e);
     const bool two_ok = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                         c->spmv_format == 1 && !c->Ab.long_rows && mk + c->m <= k::kMaxNv - 2;
-    const bool two = two_ok && (form == SPK_ITER_TWO_LAUNCH || (form == SPK_ITER_AUTO && nl < (1 << 20)));
+    const bool two = two_ok && (form == SPK_ITER_TWO_LAUNCH || form == SPK_ITER_THREE_LAUNCH ||
+                                (form == SPK_ITER_AUTO && nl < (1 << 20)));
+    // three launches: VecMDot (h and B D w) stays a launch of its own behind the SpMV.  What AUTO takes for
+    // small vectors: measured on the 1/8 slab of the 1024^2 grid 47.9 (four launches) / 44.8 (three) /
+    // 56.4 us (two: the fused SpMV + MDot kernel is a chain of latencies at <= 4 workgroups per CU);
+    // 256^2 36.2 / 30.0 / 40.1, 512^2 71.8 / 68.1 / 81.0; the full 1024^2 grid 215 / 218 / 236 (four stays)
+    const bool three = two && form != SPK_ITER_TWO_LAUNCH;
     if (two && !c->zun.p) c->zun.alloc((size_t)ld);
     const int lam_in_dot = c->comm->rank() == 0 ? 1 : 0;
 
@@ -717,7 +723,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 k::IterA a{};
                 a.browptr = c->Ab.browptr.p; a.bcol = c->Ab.bcol.p; a.vtop = c->Ab.vtop.p; a.vbot = c->Ab.vbot.p;
                 a.tile_brow = c->Ab.tile_brow.p; a.ntiles = c->Ab.ntiles; a.tiles_per_xcd = (c->Ab.ntiles + 7) / 8;
-                a.slots = k::iter_slots(a.tiles_per_xcd);
+                a.slots = 0;  // set by the launcher
                 a.od = c->n_ghost > 0 ? c->offdiag() : k::OffDiag{nullptr, nullptr, nullptr, nullptr};
                 a.zsrc = zsrc;
                 a.zdst = loc == 0 ? nullptr : Zj(loc);
@@ -730,12 +736,19 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 a.nl = nl; a.lam_in_dot = lam_in_dot;
                 a.tb = c->ka.tb; a.wl_out = wl(0);
                 a.partials = c->partials.p; a.out = db;
-                a.ar = c->comm->fused_allreduce(loc + 1 + m, k::kStatArDots);
+                if (!three) a.ar = c->comm->fused_allreduce(loc + 1 + m, k::kStatArDots);
                 a.err = c->errw.p; a.fin_ticks = c->fin_ticks;
                 a.ka = c->ka; a.loc_prev = loc - 1; a.dots_prev = dotsbuf(loc - 1); a.nrm_prev = nrmbuf(loc - 1);
                 a.done = done;
-                k::iter_spmv_mdot(a, s);
-                if (!a.ar.P) c->comm->allreduce_sum(db, loc + 1 + m, s);
+                k::iter_spmv_mdot(a, s, !three);
+                if (three) {
+                    // h = V^T w and q = B D w (dense rows, or two halves per parity-interleaved plane) in one pass
+                    const bool one = loc + 1 + m <= 40;  // beyond 40 vectors MDot is two launches: dense rows, no ride-along
+                    const k::PeerAR ar = one ? c->comm->fused_allreduce(loc + 2 + m, k::kStatArDots) : k::PeerAR{};
+                    const bool spl = bpk && one;
+                    k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, spl ? c->bdpk.p : c->bd.p, m, spl ? 1 : 0);
+                    if (!ar.P) c->comm->allreduce_sum(db, loc + 2 + m, s);
+                } else if (!a.ar.P) c->comm->allreduce_sum(db, loc + 1 + m, s);
                 const k::PeerAR ar2 = c->comm->fused_allreduce(1, k::kStatArNorm);
                 if (loc + 1 < mk) {
                     k::IterB b{};
