@@ -59,6 +59,15 @@ int64_t SpkConstraintsSlabNnz3D(int mx, int my, int mz, int64_t row_begin, int64
 int SpkAssembleOperator_Constraints3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end, int32_t *rowptr,
                                       int32_t *colidx, double *val);
 int SpkAssembleRHS_Constraints3D(double *g6);
+/* Optional divergence / pressure block for the 3-D grid (BUILD-DEFINED, in the manner of
+ * PETSc's ksp/ex42.c that the reference's help string names, main.c:1): one constraint row per hexahedron e
+ * (one constant pressure per element), B[e][(a,c)] = int_e dN_a/dx_c dV, Dirichlet columns dropped.  A general
+ * sparse A10 block: m = (mx-1)(my-1)(mz-1) rows of <= 24 entries.  All m rows restricted to the node planes
+ * [row_begin, row_end) the rank owns (column partition, like the other constraint rows); rowptr has m + 1 entries.
+ * Note: with Dirichlet data on every face the rows sum to zero on the free columns (the constant-pressure mode). */
+int64_t SpkDivergenceSlabNnz3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end);
+int SpkAssembleOperator_Divergence3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end, int32_t *rowptr,
+                                     int32_t *colidx, double *val);
 
 /* Legacy-VTK ASCII output of the solution on the node grid: what WriteVTK(da_u, u,
  * "test.vtk") at /root/reference/src/SaddlePointProblem.c:22 is meant to produce.  The

@@ -186,6 +186,23 @@ def assemble_constraints3d(mx, my=None, mz=None):
     return CSR(rowptr, colidx, val, 3 * mx * my * mz), g
 
 
+def assemble_divergence3d(mx, my=None, mz=None):
+    """Build-defined discrete divergence block (one row per hexahedron, Dirichlet columns dropped)."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    L = lib()
+    L.spo3_divergence_nnz.restype = C.c_int64
+    L.spo3_divergence_nnz.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.spo3_assemble_div.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p]
+    nnz = L.spo3_divergence_nnz(mx, my, mz)
+    m = (mx - 1) * (my - 1) * (mz - 1)
+    rowptr = np.zeros(m + 1, np.int32)
+    colidx = np.zeros(nnz, np.int32)
+    val = np.zeros(nnz)
+    L.spo3_assemble_div(mx, my, mz, rowptr, colidx, val)
+    return CSR(rowptr, colidx, val, 3 * mx * my * mz)
+
+
 def _operator(A, B=None):
     op = Operator()
     op.n = A.nrows

@@ -463,7 +463,8 @@ void spo_schur_setup(const spo_operator *op, const double *dinv, double *shat, d
     for (int32_t r = 0; r < m; ++r) {
         for (int32_t k = op->b_rowptr[r]; k < op->b_rowptr[r + 1]; ++k)
             row[op->b_colidx[k]] = op->b_val[k] * dinv[op->b_colidx[k]];
-        for (int32_t s = 0; s < m; ++s) {
+        /* without G only the diagonal is wanted (blocks with thousands of rows: O(nnz), not O(m nnz)) */
+        for (int32_t s = G ? 0 : r; s < (G ? m : r + 1); ++s) {
             double acc = 0.0;
             for (int32_t k = op->b_rowptr[s]; k < op->b_rowptr[s + 1]; ++k)
                 acc += op->b_val[k] * row[op->b_colidx[k]];
@@ -997,6 +998,53 @@ int spo3_assemble_B(int mx, int my, int mz, int32_t *rowptr, int32_t *colidx, do
     }
     rowptr[6] = (int32_t)q;
     g[0] = 1e-2; g[1] = -2e-2; g[2] = 3e-3; g[3] = 1e-3; g[4] = 2e-3; g[5] = -1e-3;
+    return 0;
+}
+
+/* BUILD-DEFINED discrete divergence block for the 3-D grid (the "optional divergence/pressure block" of
+ * SURVEY section 8(f)-3, in the manner of PETSc's ksp/ex42.c that the reference's help string points to,
+ * main.c:1; the reference itself has no constraint assembler, Discretization.c:277-290, and is 2-D): one
+ * row per hexahedron e with one constant pressure,
+ *     B[e][(a,c)] = int_e dN_a/dx_c dV = sgn_c(a) h_c' h_c'' / 4      (uniform grid),
+ * Dirichlet columns dropped like in the other constraint rows; rows in element order (ek, ej, ei),
+ * columns ascending.  A GENERAL SPARSE constraint block: thousands of short rows. */
+int64_t spo3_divergence_nnz(int mx, int my, int mz)
+{
+    int64_t q = 0;
+    for (int ek = 0; ek < mz - 1; ++ek)
+        for (int ej = 0; ej < my - 1; ++ej)
+            for (int ei = 0; ei < mx - 1; ++ei)
+                for (int dk = 0; dk < 2; ++dk)
+                    for (int dj = 0; dj < 2; ++dj)
+                        for (int di = 0; di < 2; ++di) {
+                            const int i = ei + di, j = ej + dj, k = ek + dk;
+                            if (i == 0 || i == mx - 1 || j == 0 || j == my - 1 || k == 0 || k == mz - 1) continue;
+                            q += 3;
+                        }
+    return q;
+}
+int spo3_assemble_div(int mx, int my, int mz, int32_t *rowptr, int32_t *colidx, double *val)
+{
+    const double hx = 1.0 / (mx - 1), hy = 1.0 / (my - 1), hz = 1.0 / (mz - 1);
+    const double fx = (hy * hz) / 4.0, fy = (hx * hz) / 4.0, fz = (hx * hy) / 4.0;
+    int64_t q = 0;
+    int32_t e = 0;
+    for (int ek = 0; ek < mz - 1; ++ek)
+        for (int ej = 0; ej < my - 1; ++ej)
+            for (int ei = 0; ei < mx - 1; ++ei) {
+                rowptr[e++] = (int32_t)q;
+                for (int dk = 0; dk < 2; ++dk)
+                    for (int dj = 0; dj < 2; ++dj)
+                        for (int di = 0; di < 2; ++di) {
+                            const int i = ei + di, j = ej + dj, k = ek + dk;
+                            if (i == 0 || i == mx - 1 || j == 0 || j == my - 1 || k == 0 || k == mz - 1) continue;
+                            const int32_t c0 = (int32_t)(((k * my + j) * mx + i) * 3);
+                            colidx[q] = c0;     val[q++] = di ? fx : -fx;
+                            colidx[q] = c0 + 1; val[q++] = dj ? fy : -fy;
+                            colidx[q] = c0 + 2; val[q++] = dk ? fz : -fz;
+                        }
+            }
+    rowptr[e] = (int32_t)q;
     return 0;
 }
 

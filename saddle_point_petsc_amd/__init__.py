@@ -9,7 +9,7 @@ from .csr import CSR  # noqa: F401
 from .assembly import (  # noqa: F401
     AssembleOperator_Laplace, AssembleOperator_Constraints, FormStressOperatorQ12D,
     FormLaplaceRHSQ12D, grid_sizes, partition_slab, WriteVTK,
-    AssembleOperator_Laplace3D, AssembleOperator_Constraints3D, partition_slab3d,
+    AssembleOperator_Laplace3D, AssembleOperator_Constraints3D, AssembleOperator_Divergence3D, partition_slab3d,
 )
 from .solver import (  # noqa: F401
     Context, KSP, LocalGroup, default_opts, unique_id,

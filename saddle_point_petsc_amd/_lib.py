@@ -134,6 +134,9 @@ def _load():
     L.SpkConstraintsSlabNnz3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64]
     L.SpkAssembleOperator_Constraints3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i32p, i32p, f64p]
     L.SpkAssembleRHS_Constraints3D.argtypes = [f64p]
+    L.SpkDivergenceSlabNnz3D.restype = i64
+    L.SpkDivergenceSlabNnz3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64]
+    L.SpkAssembleOperator_Divergence3D.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i32p, i32p, f64p]
     L.SpkWriteVTK.argtypes = [C.c_int, C.c_int, f64p, C.c_char_p]
     L.SpkFormStressOperatorQ12D.argtypes = [f64p, f64p, f64p]
     L.SpkFormLaplaceRHSQ12D.argtypes = [f64p, f64p]

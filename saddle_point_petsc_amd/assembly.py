@@ -113,6 +113,25 @@ def AssembleOperator_Constraints3D(mx, my=None, mz=None, row_begin=0, row_end=No
     return CSR(rowptr, colidx, val, n, 0), g
 
 
+def AssembleOperator_Divergence3D(mx, my=None, mz=None, row_begin=0, row_end=None):
+    """BUILD-DEFINED discrete divergence block of the 3-D grid (include/spk_assembly.h): one row per
+    hexahedron, all rows restricted to the columns [row_begin, row_end) -- a general sparse A10 block."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n = 3 * mx * my * mz
+    row_end = n if row_end is None else row_end
+    nz = lib.SpkDivergenceSlabNnz3D(mx, my, mz, row_begin, row_end)
+    if nz < 0:
+        raise SpkError(-1, "column range must consist of whole node planes (grid >= 3^3)")
+    m = (mx - 1) * (my - 1) * (mz - 1)
+    rowptr = np.zeros(m + 1, np.int32)
+    colidx = np.zeros(nz, np.int32)
+    val = np.zeros(nz)
+    _chk(lib.SpkAssembleOperator_Divergence3D(mx, my, mz, row_begin, row_end, rowptr, colidx, val),
+         "SpkAssembleOperator_Divergence3D")
+    return CSR(rowptr, colidx, val, n, 0)
+
+
 def WriteVTK(mx, my, u, filename):
     """Legacy-VTK file with the node grid and the solution field (the reference's
     WriteVTK, SaddlePointProblem.c:22, never wrote the field)."""

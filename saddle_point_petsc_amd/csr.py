@@ -31,6 +31,17 @@ class CSR:
         return CSR(self.rowptr[r0:r1 + 1] - k0, self.colidx[k0:k1], self.val[k0:k1], self.ncols,
                    self.row_begin + r0)
 
+    @staticmethod
+    def vstack(blocks):
+        """Rows of several blocks with the same columns, one below the other (constraint blocks)."""
+        rp = [np.zeros(1, np.int64)]
+        off = 0
+        for b in blocks:
+            rp.append(b.rowptr[1:].astype(np.int64) + off)
+            off += b.nnz
+        return CSR(np.concatenate(rp).astype(np.int32), np.concatenate([b.colidx for b in blocks]),
+                   np.concatenate([b.val for b in blocks]), blocks[0].ncols, 0)
+
     def col_slab(self, c0, c1):
         """Columns [c0, c1) of all rows (global columns kept) -- how the
         constraint block is dealt to ranks."""

@@ -542,6 +542,54 @@ int SpkAssembleOperator_Constraints3D(int mx, int my, int mz, int64_t row_begin,
     return SPK_OK;
 }
 
+// Discrete divergence block, one row per hexahedron (see include/spk_assembly.h): the entries of a row over
+// the columns [row_begin, row_end) this rank owns.
+static int64_t divergence_slab(int mx, int my, int mz, int64_t row_begin, int64_t row_end, int32_t *rowptr, int32_t *colidx,
+                               double *val)
+{
+    const double hx = 1.0 / (mx - 1), hy = 1.0 / (my - 1), hz = 1.0 / (mz - 1);
+    const double fx = (hy * hz) / 4.0, fy = (hx * hz) / 4.0, fz = (hx * hy) / 4.0;
+    int64_t q = 0;
+    int64_t e = 0;
+    for (int ek = 0; ek < mz - 1; ++ek)
+        for (int ej = 0; ej < my - 1; ++ej)
+            for (int ei = 0; ei < mx - 1; ++ei) {
+                if (rowptr) rowptr[e] = (int32_t)q;
+                ++e;
+                for (int dk = 0; dk < 2; ++dk)
+                    for (int dj = 0; dj < 2; ++dj)
+                        for (int di = 0; di < 2; ++di) {
+                            const int i = ei + di, j = ej + dj, k = ek + dk;
+                            if (i == 0 || i == mx - 1 || j == 0 || j == my - 1 || k == 0 || k == mz - 1) continue;
+                            const int64_t c0 = (((int64_t)k * my + j) * mx + i) * 3;
+                            if (c0 < row_begin || c0 >= row_end) continue;   // whole nodes belong to one rank
+                            if (colidx) {
+                                colidx[q] = (int32_t)c0;       val[q] = di ? fx : -fx;
+                                colidx[q + 1] = (int32_t)c0 + 1; val[q + 1] = dj ? fy : -fy;
+                                colidx[q + 2] = (int32_t)c0 + 2; val[q + 2] = dk ? fz : -fz;
+                            }
+                            q += 3;
+                        }
+            }
+    if (rowptr) rowptr[e] = (int32_t)q;
+    return q;
+}
+
+int64_t SpkDivergenceSlabNnz3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end)
+{
+    const int64_t plane = (int64_t)3 * mx * my;
+    if (mx < 3 || my < 3 || mz < 3 || row_begin % plane || row_end % plane || row_begin > row_end || row_end > plane * mz) return -1;
+    return divergence_slab(mx, my, mz, row_begin, row_end, nullptr, nullptr, nullptr);
+}
+
+int SpkAssembleOperator_Divergence3D(int mx, int my, int mz, int64_t row_begin, int64_t row_end, int32_t *rowptr,
+                                     int32_t *colidx, double *val)
+{
+    if (!rowptr || !colidx || !val || SpkDivergenceSlabNnz3D(mx, my, mz, row_begin, row_end) < 0) return SPK_ERR_ARG;
+    divergence_slab(mx, my, mz, row_begin, row_end, rowptr, colidx, val);
+    return SPK_OK;
+}
+
 int SpkAssembleRHS_Constraints3D(double *g)
 {
     if (!g) return SPK_ERR_ARG;

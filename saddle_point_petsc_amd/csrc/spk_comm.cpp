@@ -209,14 +209,16 @@ public:
     void allreduce_sum(double *dev, int count, hipStream_t s) override
     {
         if (count <= 0) return;
-        if (count > 256) fail(SPK_ERR_COMM, "local all-reduce limited to 256 values");
-        SPK_HIP(hipMemcpyAsync(g_->slots + 256 * (size_t)rank_, dev, sizeof(double) * (size_t)count,
-                               hipMemcpyDeviceToDevice, s));
-        SPK_HIP(hipStreamSynchronize(s));
-        g_->barrier();
-        k::sum_slots(g_->slots, g_->nranks, 256, count, dev, s);
-        SPK_HIP(hipStreamSynchronize(s));
-        g_->barrier();
+        for (int off = 0; off < count; off += 256) {  // slots of 256 values per rank: longer payloads in pieces
+            const int cnt = std::min(256, count - off);
+            SPK_HIP(hipMemcpyAsync(g_->slots + 256 * (size_t)rank_, dev + off, sizeof(double) * (size_t)cnt,
+                                   hipMemcpyDeviceToDevice, s));
+            SPK_HIP(hipStreamSynchronize(s));
+            g_->barrier();
+            k::sum_slots(g_->slots, g_->nranks, 256, cnt, dev + off, s);
+            SPK_HIP(hipStreamSynchronize(s));
+            g_->barrier();
+        }
     }
     void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                   double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override

@@ -320,7 +320,10 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
                const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
 // f.out[r] = B_r . x, r < m
-void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s);
+void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s,
+              const int32_t *rowmap = nullptr);
+// shat[r] = sum_k B_rk^2 dinv[col_k], one wave per CSR row
+void schur_diag_rows(const CsrDev &B, const double *dinv, double *shat, hipStream_t s);
 // same with x replaced by x .* dinv (the B D x0 step of the Schur PC, no stored D x0)
 void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, const Finish &f,
                      const int32_t *done, hipStream_t s);
@@ -516,9 +519,17 @@ struct spk_ctx {
     spk::k::OffDiag offdiag() const { return spk::k::OffDiag{ao_rowptr_full.p, Ao.colidx.p, Ao.val.p, xghost.p}; }
     bool have_A = false, have_B = false;
 
-    // constraint block: B (m x n_local) in column windows, B^T (n_local x m) by rows
+    // constraint block: B^T (n_local x m) by rows, always; B itself
+    //   m <= 8        : every row in column windows (WideDev) -- the long-row kernel, and the fused dense-plane path
+    //   m  > 8        : a general sparse block: CSR by rows (Bc, the stream kernel) with up to 8 LONG rows (more than
+    //                   kWideRowNnz local entries) taken out into the windowed form (B, rows listed in wide_rows)
     spk::WideDev B;
-    spk::CsrDev Bt;
+    spk::CsrDev Bt, Bc;
+    bool b_general = false;
+    int m_wide = 0;
+    spk::DevBuf<int32_t> wide_rows;
+    std::vector<int32_t> wide_rows_h;
+    spk::DevBuf<double> tmpb;  // scratch vector of the general block's D x0 products
 
     // halo plan
     std::vector<int> peers;

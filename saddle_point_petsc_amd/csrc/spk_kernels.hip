@@ -563,8 +563,10 @@ __global__ __launch_bounds__(kVT) void wide_dot_kernel(
     const int32_t *__restrict__ colidx, const double *__restrict__ val,
     const int32_t *__restrict__ winptr, int m, int nwin, const double *__restrict__ x,
     const double *__restrict__ scale, double *__restrict__ partials,
-    double *__restrict__ out, FinErr fe, const int32_t *__restrict__ done)
+    double *__restrict__ out, const int32_t *__restrict__ rowmap, FinErr fe, const int32_t *__restrict__ done)
 {
+    // rowmap != nullptr: the m rows here are the LONG rows of a larger constraint block (the short ones go
+    // through the CSR stream kernel); row r of this launch is row rowmap[r] of the block
     if (done && *done) return;
     __shared__ double scratch[kVT];
     const int w = blockIdx.x;
@@ -598,24 +600,49 @@ __global__ __launch_bounds__(kVT) void wide_dot_kernel(
     }
     if (!arrive_last(gridDim.x)) return;
     final_reduce(partials, nwin, kPartialLd, m, scratch, fe);
-    if ((int)threadIdx.x < m) out[threadIdx.x] = scratch[threadIdx.x];
+    if ((int)threadIdx.x < m) out[rowmap ? rowmap[threadIdx.x] : (int)threadIdx.x] = scratch[threadIdx.x];
 }
 
 static void wide_dot_scaled(const WideDev &B, const double *x, const double *scale, const Finish &f,
-                            const int32_t *done, hipStream_t s)
+                            const int32_t *done, hipStream_t s, const int32_t *rowmap)
 {
     if (B.nwin == 0) return;
     hipLaunchKernelGGL(wide_dot_kernel, dim3(B.nwin), dim3(kVT), 0, s, B.colidx.p, B.val.p,
-                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
+                       B.winptr.p, B.m, B.nwin, x, scale, f.partials, f.out, rowmap, FinErr{f.err, f.fin_ticks}, done);
 }
-void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s)
+void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s, const int32_t *rowmap)
 {
-    wide_dot_scaled(B, x, nullptr, f, done, s);
+    wide_dot_scaled(B, x, nullptr, f, done, s, rowmap);
 }
 void wide_dot_jacobi(const WideDev &B, const double *x, const double *dinv, const Finish &f,
                      const int32_t *done, hipStream_t s)
 {
-    wide_dot_scaled(B, x, dinv, f, done, s);
+    wide_dot_scaled(B, x, dinv, f, done, s, nullptr);
+}
+
+// S^_r = sum_k B_rk^2 dinv[col_k] for the rows of a CSR block, one wave per row (lanes stride the row, fixed
+// shuffle tree: reproducible).  PCFIELDSPLIT's selfp Schur complement restricted to its diagonal, for constraint
+// blocks with many short rows (the few long rows of such a block go through scatter_row + wide_dot).
+__global__ __launch_bounds__(kThreads) void schur_diag_rows_kernel(const int32_t *__restrict__ rowptr,
+                                                                   const int32_t *__restrict__ colidx,
+                                                                   const double *__restrict__ val, int nrows,
+                                                                   const double *__restrict__ dinv,
+                                                                   double *__restrict__ shat)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    double acc = 0.0;
+    for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += kWave) acc += val[k] * val[k] * dinv[colidx[k]];
+    const double sr = wave_sum(acc);
+    if (lane == 0) shat[r] = sr;
+}
+void schur_diag_rows(const CsrDev &B, const double *dinv, double *shat, hipStream_t s)
+{
+    if (B.nrows == 0) return;
+    const int wpb = kThreads / kWave;
+    hipLaunchKernelGGL(schur_diag_rows_kernel, dim3((B.nrows + wpb - 1) / wpb), dim3(kThreads), 0, s, B.rowptr.p,
+                       B.colidx.p, B.val.p, B.nrows, dinv, shat);
 }
 
 // ---------------------------------------------------------------------------
@@ -1715,7 +1742,7 @@ __global__ void schur_y1_kernel(int fact, int m, const double *__restrict__ x1,
                                 double *__restrict__ y1, const int32_t *__restrict__ done)
 {
     if (done && *done) return;
-    const int r = threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
     double v;
     if (fact == SPK_SCHUR_DIAG) v = x1[r] / shat[r];
@@ -1727,19 +1754,19 @@ void schur_y1(int fact, int m, const double *x1, const double *t, const double *
               const int32_t *done, hipStream_t s)
 {
     if (m == 0) return;
-    hipLaunchKernelGGL(schur_y1_kernel, dim3(1), dim3(64), 0, s, fact, m, x1, t, shat, y1, done);
+    hipLaunchKernelGGL(schur_y1_kernel, dim3((m + 63) / 64), dim3(64), 0, s, fact, m, x1, t, shat, y1, done);
 }
 
 __global__ void copy_small_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
                                   const int32_t *__restrict__ done)
 {
     if (done && *done) return;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 void copy_small(const double *src, double *dst, int n, const int32_t *done, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(copy_small_kernel, dim3(1), dim3(64), 0, s, src, dst, n, done);
+    hipLaunchKernelGGL(copy_small_kernel, dim3(n > 4096 ? 16 : 1), dim3(n > 64 ? 256 : 64), 0, s, src, dst, n, done);
 }
 
 // dense scatter of one B row scaled by dinv (set-up of S^ and G only)

@@ -296,7 +296,10 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
 {
     if (!c->have_A) fail(SPK_ERR_STATE, "A10: set SPK_BLOCK_A00 first");
     if (ncols_global != c->n_global) fail(SPK_ERR_ARG, "A10: %lld columns, A00 has %lld", (long long)ncols_global, (long long)c->n_global);
-    if (m < 0 || m > 8) fail(SPK_ERR_UNSUPPORTED, "A10: m=%d rows; the long-row path supports m <= 8", m);
+    if (m < 0) fail(SPK_ERR_ARG, "A10: negative row count");
+    if ((int64_t)c->n_local + m > INT32_MAX - 1024) fail(SPK_ERR_UNSUPPORTED, "A10: n_local + m exceeds 32-bit vector indices");
+    for (int32_t r = 0; r < m; ++r)
+        if (rowptr[r + 1] < rowptr[r]) fail(SPK_ERR_ARG, "A10: rowptr not monotone at row %d", r);
     const int32_t nl = c->n_local;
     const int64_t lo = c->row_begin, hi = lo + nl;
     // local column numbers, ascending inside each row
@@ -315,26 +318,77 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
             v[(size_t)(k0 + i)] = val[perm[(size_t)i]];
         }
     }
-    // column windows
+    // Which rows go through the column-window (long-row) kernel: all of them for m <= 8 (the reference's 4
+    // rows, the fused dense-plane path); for a general block only its LONG rows (local entries beyond
+    // kWideRowNnz; at most 8, the longest first) -- the rest is a CSR by rows for the stream kernel.
+    constexpr int32_t kWideRowNnz = 8192;
+    c->b_general = m > 8;
+    std::vector<int32_t> wide;
+    if (!c->b_general) {
+        for (int32_t r = 0; r < m; ++r) wide.push_back(r);
+    } else {
+        std::vector<int32_t> cand;
+        for (int32_t r = 0; r < m; ++r)
+            if (rowptr[r + 1] - rowptr[r] > kWideRowNnz) cand.push_back(r);
+        std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) {
+            const int32_t la = rowptr[a + 1] - rowptr[a], lb = rowptr[b + 1] - rowptr[b];
+            return la != lb ? la > lb : a < b;
+        });
+        if (cand.size() > 8) cand.resize(8);
+        std::sort(cand.begin(), cand.end());
+        wide = cand;
+    }
+    const int32_t mw = (int32_t)wide.size();
+    c->m_wide = mw;
+    c->wide_rows_h = wide;
+    c->wide_rows.upload(wide.data(), wide.size(), 8);
+    // column windows over the wide rows (concatenated in `wide` order)
     WideDev &B = c->B;
-    B.m = m;
+    B.m = mw;
     B.ncols = nl;
-    B.nnz = rowptr[m];
+    std::vector<int32_t> wcol, wrp(1, 0);
+    std::vector<double> wv;
+    for (int32_t r : wide) {
+        wcol.insert(wcol.end(), col.begin() + rowptr[r], col.begin() + rowptr[r + 1]);
+        wv.insert(wv.end(), v.begin() + rowptr[r], v.begin() + rowptr[r + 1]);
+        wrp.push_back((int32_t)wcol.size());
+    }
+    B.nnz = (int64_t)wcol.size();
     int32_t win = 8192;
     while ((int64_t)(nl + win - 1) / win > k::kMaxBlocks) win *= 2;
     B.win = win;
-    B.nwin = m > 0 ? (nl + win - 1) / win : 0;
-    std::vector<int32_t> winptr((size_t)(B.nwin + 1) * (size_t)std::max(m, 1));
-    for (int32_t r = 0; r < m; ++r) {
-        const int32_t *b = col.data() + rowptr[r], *e = col.data() + rowptr[r + 1];
+    B.nwin = mw > 0 ? (nl + win - 1) / win : 0;
+    std::vector<int32_t> winptr((size_t)(B.nwin + 1) * (size_t)std::max(mw, 1));
+    for (int32_t r = 0; r < mw; ++r) {
+        const int32_t *b = wcol.data() + wrp[(size_t)r], *e = wcol.data() + wrp[(size_t)r + 1];
         for (int32_t w = 0; w <= B.nwin; ++w) {
             const int64_t c0 = (int64_t)w * win;
-            winptr[(size_t)w * m + r] = rowptr[r] + (int32_t)(std::lower_bound(b, e, (int32_t)std::min<int64_t>(c0, nl)) - b);
+            winptr[(size_t)w * mw + r] = wrp[(size_t)r] + (int32_t)(std::lower_bound(b, e, (int32_t)std::min<int64_t>(c0, nl)) - b);
         }
     }
-    B.colidx.upload(col.data(), col.size(), 16);
-    B.val.upload(v.data(), v.size(), 16);
+    B.colidx.upload(wcol.data(), wcol.size(), 16);
+    B.val.upload(wv.data(), wv.size(), 16);
     B.winptr.upload(winptr.data(), winptr.size(), 8);
+    // the general block by rows (its long rows left empty: the window kernel fills their results in)
+    c->Bc.rowptr.release(); c->Bc.colidx.release(); c->Bc.val.release(); c->Bc.tile_row.release();
+    c->Bc.nrows = c->Bc.ncols = c->Bc.ntiles = 0;
+    c->Bc.nnz = 0;
+    if (c->b_general) {
+        std::vector<char> is_wide((size_t)m, 0);
+        for (int32_t r : wide) is_wide[(size_t)r] = 1;
+        std::vector<int32_t> crp((size_t)m + 1, 0), cci;
+        std::vector<double> cv;
+        for (int32_t r = 0; r < m; ++r) {
+            if (!is_wide[(size_t)r]) {
+                cci.insert(cci.end(), col.begin() + rowptr[r], col.begin() + rowptr[r + 1]);
+                cv.insert(cv.end(), v.begin() + rowptr[r], v.begin() + rowptr[r + 1]);
+            }
+            crp[(size_t)r + 1] = (int32_t)cci.size();
+        }
+        upload_csr(c->Bc, m, nl, crp, cci, cv, true);
+    }
+    if ((size_t)m + 64 > c->y1tmp.n) c->y1tmp.alloc((size_t)m + 64);
+    if ((size_t)m + 64 > c->ttmp.n) c->ttmp.alloc((size_t)m + 64);
 
     // B^T by rows (n_local x m), entries of a row ordered by constraint index
     std::vector<int32_t> trp((size_t)nl + 1, 0), tci((size_t)rowptr[m]);
@@ -378,6 +432,27 @@ void set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, in
     } else fail(SPK_ERR_ARG, "set_block: unknown block %d", which);
 }
 
+// out[r] = B_r . (x .* scale)  over this rank's columns (scale == nullptr: B_r . x); MatMult on the (1,0) block.
+// m <= 8: the column-window kernel for every row.  General block: short rows row by row through the CSR
+// stream kernel, its few long rows through the window kernel (results scattered to their row numbers).
+static void apply_B(spk_ctx *c, const double *x, const double *scale, double *out, const int32_t *done)
+{
+    hipStream_t s = c->stream;
+    if (!c->b_general) {
+        if (scale) k::wide_dot_jacobi(c->B, x, scale, c->fin(out), done, s);
+        else k::wide_dot(c->B, x, c->fin(out), done, s);
+        return;
+    }
+    const double *xs = x;
+    if (scale) {  // D x0 as a vector of its own (the fused forms that avoid it are for the reference's 4 rows)
+        if (c->tmpb.n < (size_t)c->ld) c->tmpb.alloc((size_t)c->ld);
+        k::jacobi(scale, x, c->tmpb.p, c->n_local, done, s);
+        xs = c->tmpb.p;
+    }
+    k::spmv(c->Bc, xs, out, nullptr, nullptr, done, s);
+    if (c->m_wide > 0) k::wide_dot(c->B, xs, c->fin(out), done, s, c->wide_rows.p);
+}
+
 // ---------------------------------------------------------------------------
 // y = K x   (MatMult_Nest over MatMult_MPIAIJ blocks)
 // ---------------------------------------------------------------------------
@@ -394,7 +469,7 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool h
     if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
     else k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
     if (m > 0) {
-        k::wide_dot(c->B, x, c->fin(y + nl), done, s);
+        apply_B(c, x, nullptr, y + nl, done);
         c->comm->allreduce_sum(y + nl, m, s);
     }
 }
@@ -414,7 +489,30 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     c->dinv.alloc((size_t)c->n_local, 8);
     k::extract_diag_inv(c->Ad, c->dinv.p, s);
     const int m = c->m;
-    if (m > 0) {
+    if (m > 0 && c->b_general) {
+        // S^ = diag(B D B^T), row by row: short rows one wave each; the long rows as below (scatter + window kernel)
+        c->gram.release();
+        c->shat.alloc((size_t)m, 8);
+        k::schur_diag_rows(c->Bc, c->dinv.p, c->shat.p, s);
+        if (c->m_wide > 0) {
+            const int mw = c->m_wide;
+            DevBuf<double> grow;
+            grow.alloc((size_t)mw);
+            SPK_HIP(hipMemsetAsync(c->tmp.p, 0, sizeof(double) * (size_t)c->ld, s));
+            std::vector<int32_t> wp((size_t)(c->B.nwin + 1) * mw);
+            SPK_HIP(hipMemcpy(wp.data(), c->B.winptr.p, wp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int r = 0; r < mw; ++r) {
+                const int k0 = wp[(size_t)r], k1 = wp[(size_t)c->B.nwin * mw + r];
+                k::scatter_row(c->B.colidx.p, c->B.val.p, k0, k1, c->dinv.p, c->tmp.p, s);
+                k::wide_dot(c->B, c->tmp.p, c->fin(grow.p), nullptr, s);          // row r of the long rows' Gram matrix
+                SPK_HIP(hipMemcpyAsync(c->shat.p + c->wide_rows_h[(size_t)r], grow.p + r, sizeof(double), hipMemcpyDeviceToDevice, s));
+                k::scatter_row(c->B.colidx.p, c->B.val.p, k0, k1, nullptr, c->tmp.p, s);
+            }
+            SPK_HIP(hipStreamSynchronize(s));
+        }
+        c->comm->allreduce_sum(c->shat.p, m, s);
+        SPK_HIP(hipStreamSynchronize(s));
+    } else if (m > 0) {
         c->gram.alloc((size_t)m * m);
         c->shat.alloc((size_t)m);
         // row r of B .* dinv scattered densely, then B * that = G[r, :]
@@ -447,7 +545,7 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     }
     // dense rows of B D for the fused path (Schur LOWER/FULL, even local size)
     c->bd.release();
-    if (pc_type == SPK_PC_SCHUR && m > 0 && (schur_fact == SPK_SCHUR_FULL || schur_fact == SPK_SCHUR_LOWER) &&
+    if (pc_type == SPK_PC_SCHUR && m > 0 && !c->b_general && (schur_fact == SPK_SCHUR_FULL || schur_fact == SPK_SCHUR_LOWER) &&
         c->n_local % 2 == 0 && c->inner_sweeps == 0) {
         c->bd.alloc((size_t)c->ld * m, 16);
         k::build_bd(c->Bt, c->dinv.p, m, c->ld, c->bd.p, s);
@@ -520,7 +618,7 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
             break;
         default:  // LOWER, FULL
             inner_apply(c, x0, y0, 0, done);
-            k::wide_dot(c->B, y0, c->fin(c->ttmp.p), done, s);
+            apply_B(c, y0, nullptr, c->ttmp.p, done);
             c->comm->allreduce_sum(c->ttmp.p, m, s);
             k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
             if (c->schur_fact == SPK_SCHUR_FULL) {
@@ -551,8 +649,8 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
         break;
     case SPK_SCHUR_LOWER:
     default:  // FULL
-        // t = B (D x0) without storing D x0
-        k::wide_dot_jacobi(c->B, x0, c->dinv.p, c->fin(c->ttmp.p), done, s);
+        // t = B (D x0) (without storing D x0 for the reference's few long rows)
+        apply_B(c, x0, c->dinv.p, c->ttmp.p, done);
         c->comm->allreduce_sum(c->ttmp.p, m, s);
         k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
         if (c->schur_fact == SPK_SCHUR_LOWER) k::jacobi(c->dinv.p, x0, y0, nl, done, s);
