@@ -479,7 +479,7 @@ void spo_schur_setup(const spo_operator *op, const double *dinv, double *shat, d
 typedef struct {
     const spo_operator *op;
     int pc_type, schur_fact;
-    double *dinv, *shat, *t0;
+    double *dinv, *shat, *t0, *t1;  /* t1: m-vector scratch (B y0) */
     int inner_its;
     double inner_omega;
     float *a32, *d32, *x32, *y32, *z32;
@@ -539,7 +539,7 @@ void spo_pc_apply(const spo_pc *pc, const double *x, double *y)
     /* Schur */
     const double *x0 = x, *x1 = x + n;
     double *y0 = y, *y1 = y + n;
-    double t[16];
+    double *t = pc->t1;
     switch (pc->schur_fact) {
     case SPO_SCHUR_DIAG:
         spo_inner_apply(pc, x0, y0);
@@ -590,7 +590,8 @@ static void spo_pc_create(spo_pc *pc, const spo_operator *op, int pc_type, int s
     pc->inner_omega = inner_omega;
     pc->dinv = (double *)malloc(sizeof(double) * (size_t)op->n);
     pc->t0 = (double *)malloc(sizeof(double) * (size_t)op->n);
-    pc->shat = (double *)calloc(16, sizeof(double));
+    pc->shat = (double *)calloc((size_t)(op->m > 16 ? op->m : 16), sizeof(double));   /* any number of constraint rows */
+    pc->t1 = (double *)calloc((size_t)(op->m > 16 ? op->m : 16), sizeof(double));
     spo_jacobi_setup(op, pc->dinv);
     if (op->m > 0) spo_schur_setup(op, pc->dinv, pc->shat, NULL);
     if (inner_its > 0) {
@@ -606,7 +607,7 @@ static void spo_pc_create(spo_pc *pc, const spo_operator *op, int pc_type, int s
 }
 static void spo_pc_free(spo_pc *pc)
 {
-    free(pc->dinv); free(pc->t0); free(pc->shat);
+    free(pc->dinv); free(pc->t0); free(pc->shat); free(pc->t1);
     free(pc->a32); free(pc->d32); free(pc->x32); free(pc->y32); free(pc->z32);
 }
 

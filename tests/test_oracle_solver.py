@@ -190,3 +190,23 @@ def test_converged_default_reference_norm(oracle):
     # zero guess: DTOL can only come from growth during the iteration; a tiny divtol triggers it at iteration 0
     x, info = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, rtol=1e-12, dtol=0.5)
     assert info["reason"] == -4 and info["its"] == 0
+
+
+@pytest.mark.parametrize("fact", [0, 1, 2, 3])
+def test_general_constraint_block_against_dense_algebra(oracle, fact):
+    """A general sparse A10 block (40 rows, far beyond the build-defined 4): every factorisation against the
+    dense block inverse, S^ against diag(B D B^T), and a converged solve against scipy's sparse LU."""
+    A, f = oracle.assemble(7, 6)
+    n, m = A.nrows, 40
+    rng = np.random.default_rng(7)
+    Bd = np.where(rng.random((m, n)) < 0.2, rng.standard_normal((m, n)), 0.0)
+    rp = np.concatenate([[0], np.cumsum((Bd != 0).sum(1))]).astype(np.int32)
+    B = oracle.CSR(rp, np.concatenate([np.nonzero(r)[0] for r in Bd]).astype(np.int32), Bd[Bd != 0], n)
+    v = rng.standard_normal(n + m)
+    assert relerr(oracle.pc_apply(A, B, oracle.PC_SCHUR, fact, v), _dense_pc(A, B, fact) @ v) < 1e-12
+    D = 1.0 / A.to_scipy().diagonal()
+    assert np.allclose(oracle.schur_setup(A, B)[0], np.einsum("ri,i,ri->r", Bd, D, Bd), rtol=1e-13)
+    K = sp.bmat([[A.to_scipy(), B.to_scipy().T], [B.to_scipy(), None]], format="csc")
+    rhs = np.concatenate([f, 1e-3 * rng.standard_normal(m)])
+    x, info = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=fact, rtol=1e-11, max_it=5000)
+    assert info["reason"] == 2 and relerr(x, sla.spsolve(K, rhs)) < 1e-8
