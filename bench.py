@@ -178,8 +178,10 @@ def main():
         if saddle:
             B, g = S.AssembleOperator_Constraints(M, My, rb, re_)
     t_asm = time.time() - t_asm
+    t_ctx = time.time()
+    ctx = S.Context(local_rank)     # HIP runtime start-up + stream + scratch: per process, not per KSPSetOperators
+    t_ctx = time.time() - t_ctx
     t_up = time.time()
-    ctx = S.Context(local_rank)
     if use_dist and os.environ.get("SPK_BENCH_COMM") == "gloo":
         ctx.comm_init_torch(dist, rank, world)
     elif use_dist:
@@ -356,7 +358,7 @@ def main():
         "value_with_host_vectors": host_rate,
         "single_reduction_mode": single_mode,
         "setup_seconds": t_setup,
-        "setup_breakdown": {"host_assembly": t_asm, "set_operators_upload": t_up, "pc_setup": t_pc},
+        "setup_breakdown": {"host_assembly": t_asm, "context_create": t_ctx, "set_operators_upload": t_up, "pc_setup": t_pc},
         # achieved = ALGORITHMIC (CSR) bytes / time.  When the kernel streams the
         # 2x2-blocked layout its true bytes are fewer: both rates are reported and `frac` is the
         # LOWER of the two fractions, as SURVEY 8(d) prescribes for compressed layouts.

@@ -98,6 +98,10 @@ int spk_destroy(spk_ctx *c)
     }
     c->comm.reset();
     hipStream_t s = c->stream;
+    for (int i = 0; i < 2; ++i) {
+        if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+    }
     delete c;  // DevBuf destructors free device memory
     if (s) (void)hipStreamDestroy(s);
     return SPK_OK;

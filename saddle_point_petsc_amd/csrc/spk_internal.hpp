@@ -66,6 +66,16 @@ struct DevBuf {
         SPK_HIP(hipMalloc((void **)&p, bytes));
         SPK_HIP(hipMemset(p, 0, bytes));
     }
+    // allocates without clearing (the caller writes every element it reads; only the pad is zeroed)
+    void alloc_raw(size_t count, size_t pad = 0)
+    {
+        release();
+        n = count;
+        size_t bytes = (count + pad) * sizeof(T);
+        if (bytes == 0) bytes = sizeof(T);
+        SPK_HIP(hipMalloc((void **)&p, bytes));
+        if (pad) SPK_HIP(hipMemset(p + count, 0, pad * sizeof(T)));
+    }
     void upload(const T *h, size_t count, size_t pad = 0)
     {
         alloc(count, pad);
@@ -319,6 +329,14 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
 void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
                const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
+// KSPSetOperators on the device: count off-rank entries per row, exclusive scan, split, 2x2 blocking
+void csr_count_off(const int32_t *rowptr, const int32_t *colidx, int nrows, int64_t lo, int64_t hi, int64_t ncols, int32_t *cnt,
+                   int32_t *bad, hipStream_t s);
+void exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int32_t *scratch, hipStream_t s);  // out[0..n]; scratch: n/2048 + 2 ints
+void csr_split(const int32_t *rowptr, const int32_t *colidx, const double *val, int nrows, int64_t lo, int64_t hi,
+               const int32_t *orp, int32_t *d_rowptr, int32_t *d_col, double *d_val, int32_t *o_col, double *o_val, hipStream_t s);
+void bcsr_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, int32_t *browptr, int32_t *bcol, double *vtop,
+               double *vbot, int32_t *fail, hipStream_t s);
 // f.out[r] = B_r . x, r < m
 void wide_dot(const WideDev &B, const double *x, const Finish &f, const int32_t *done, hipStream_t s,
               const int32_t *rowmap = nullptr);
@@ -574,6 +592,10 @@ struct spk_ctx {
 
     void ensure_scratch();
     void ensure_vectors();
+    // pageable host memory -> device through two pinned staging buffers (KSPSetOperators)
+    void upload_staged(void *dst, const void *src, size_t bytes);
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
 
 namespace spk {

@@ -554,6 +554,190 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
 }
 
 // ---------------------------------------------------------------------------
+// KSPSetOperators on the device (set-up must not dwarf the solve).  The caller's CSR slab is
+// uploaded once as it is; what MatMPIAIJ does at assembly time -- the split into a diagonal block with local
+// column numbers and an off-rank block -- and the 2x2 blocking run here, one thread per (block) row, entry
+// order kept (the SpMV sums stay in CSR order: bitwise parity with the oracle).
+// ---------------------------------------------------------------------------
+// cnt[r] = entries of row r with a column outside [lo, hi); *bad = a column outside [0, ncols)
+__global__ __launch_bounds__(kThreads) void csr_count_off_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                                 int nrows, int64_t lo, int64_t hi, int64_t ncols,
+                                                                 int32_t *__restrict__ cnt, int32_t *__restrict__ bad)
+{
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= nrows) return;
+    int32_t no = 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int64_t c = colidx[k];
+        if (c < 0 || c >= ncols) {
+            bad[0] = 1;
+            bad[1] = (int32_t)c;
+        }
+        no += (c < lo || c >= hi);
+    }
+    cnt[r] = no;
+}
+void csr_count_off(const int32_t *rowptr, const int32_t *colidx, int nrows, int64_t lo, int64_t hi, int64_t ncols, int32_t *cnt,
+                   int32_t *bad, hipStream_t s)
+{
+    if (nrows == 0) return;
+    hipLaunchKernelGGL(csr_count_off_kernel, dim3((nrows + kThreads - 1) / kThreads), dim3(kThreads), 0, s, rowptr, colidx, nrows,
+                       lo, hi, ncols, cnt, bad);
+}
+
+// exclusive prefix sum of n int32 counts into out[0..n] (out[n] = total), three small kernels
+constexpr int kScanItems = 8;
+__global__ __launch_bounds__(kThreads) void scan_block_kernel(const int32_t *__restrict__ in, int64_t n, int32_t *__restrict__ out,
+                                                              int32_t *__restrict__ block_sum)
+{
+    __shared__ int32_t lds[kThreads];
+    const int64_t base = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * kScanItems;
+    int32_t v[kScanItems], tot = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        tot += v[i];
+    }
+    lds[threadIdx.x] = tot;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {  // Hillis-Steele over the thread totals
+        const int32_t add = (int)threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
+        __syncthreads();
+        lds[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int32_t run = lds[threadIdx.x] - tot;  // exclusive prefix of this thread inside the block
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == kThreads - 1) block_sum[blockIdx.x] = lds[threadIdx.x];
+}
+__global__ __launch_bounds__(kThreads) void scan_sums_kernel(int32_t *__restrict__ block_sum, int nblocks, int32_t *__restrict__ total)
+{
+    __shared__ int32_t lds[kThreads];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += kThreads) {
+        const int i = b0 + threadIdx.x;
+        const int32_t v = i < nblocks ? block_sum[i] : 0;
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kThreads; off <<= 1) {
+            const int32_t add = (int)threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
+            __syncthreads();
+            lds[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sum[i] = carry + lds[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) carry += lds[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(kThreads) void scan_add_kernel(int32_t *__restrict__ out, int64_t n, const int32_t *__restrict__ block_sum,
+                                                            const int32_t *__restrict__ total)
+{
+    const int64_t base = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * kScanItems;
+    const int32_t add = block_sum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+        if (base + i < n) out[base + i] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+void exclusive_scan_i32(const int32_t *in, int64_t n, int32_t *out, int32_t *scratch, hipStream_t s)
+{
+    // scratch: ceil(n / 2048) + 1 ints
+    const int nb = (int)((n + (int64_t)kThreads * kScanItems - 1) / ((int64_t)kThreads * kScanItems));
+    if (nb == 0) {
+        (void)hipMemsetAsync(out, 0, sizeof(int32_t), s);
+        return;
+    }
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(kThreads), 0, s, in, n, out, scratch);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kThreads), 0, s, scratch, nb, scratch + nb);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(kThreads), 0, s, out, n, scratch, scratch + nb);
+}
+
+// the split itself: row r's diagonal entries (column - lo) to d_* at rowptr[r] - orp[r], its off-rank entries
+// (GLOBAL column, renumbered by the host afterwards) to o_* at orp[r]; order inside a row kept
+__global__ __launch_bounds__(kThreads) void csr_split_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                             const double *__restrict__ val, int nrows, int64_t lo, int64_t hi,
+                                                             const int32_t *__restrict__ orp, int32_t *__restrict__ d_rowptr,
+                                                             int32_t *__restrict__ d_col, double *__restrict__ d_val,
+                                                             int32_t *__restrict__ o_col, double *__restrict__ o_val)
+{
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r > nrows) return;
+    if (r == nrows) {
+        d_rowptr[r] = rowptr[r] - orp[r];
+        return;
+    }
+    int kd = rowptr[r] - orp[r], ko = orp[r];
+    d_rowptr[r] = kd;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int64_t c = colidx[k];
+        if (c >= lo && c < hi) {
+            d_col[kd] = (int32_t)(c - lo);
+            d_val[kd++] = val[k];
+        } else {
+            o_col[ko] = (int32_t)c;
+            o_val[ko++] = val[k];
+        }
+    }
+}
+void csr_split(const int32_t *rowptr, const int32_t *colidx, const double *val, int nrows, int64_t lo, int64_t hi,
+               const int32_t *orp, int32_t *d_rowptr, int32_t *d_col, double *d_val, int32_t *o_col, double *o_val, hipStream_t s)
+{
+    hipLaunchKernelGGL(csr_split_kernel, dim3((nrows + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, rowptr, colidx, val, nrows,
+                       lo, hi, orp, d_rowptr, d_col, d_val, o_col, o_val);
+}
+
+// 2x2 blocking: block row br = rows 2 br, 2 br + 1, which must share their column pattern with the columns in
+// pairs (2c, 2c+1); then block q of the row starts at rowptr[2 br] / 4.  *fail is raised when the structure does
+// not hold anywhere (the CSR stream kernel is used then).
+__global__ __launch_bounds__(kThreads) void bcsr_fill_kernel(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                             const double *__restrict__ va, int nbr, int32_t *__restrict__ browptr,
+                                                             int32_t *__restrict__ bcol, double *__restrict__ vtop,
+                                                             double *__restrict__ vbot, int32_t *__restrict__ fail)
+{
+    const int br = blockIdx.x * kThreads + threadIdx.x;
+    if (br > nbr) return;
+    if (br == nbr) {
+        browptr[br] = rp[2 * nbr] / 4;
+        return;
+    }
+    const int r = 2 * br;
+    const int k0 = rp[r], k1 = rp[r + 1], l0 = k1, l1 = rp[r + 2];
+    if ((k1 - k0) != (l1 - l0) || ((k1 - k0) & 1) || (k0 & 3)) {
+        *fail = 1;
+        return;
+    }
+    browptr[br] = k0 / 4;
+    int64_t q = k0 / 4;
+    for (int k = 0; k < k1 - k0; k += 2, ++q) {
+        const int c0 = ci[k0 + k], c1 = ci[k0 + k + 1];
+        if ((c0 & 1) || c1 != c0 + 1 || ci[l0 + k] != c0 || ci[l0 + k + 1] != c1) {
+            *fail = 1;
+            return;
+        }
+        bcol[q] = c0 >> 1;
+        vtop[2 * q] = va[k0 + k];
+        vtop[2 * q + 1] = va[k0 + k + 1];
+        vbot[2 * q] = va[l0 + k];
+        vbot[2 * q + 1] = va[l0 + k + 1];
+    }
+}
+void bcsr_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, int32_t *browptr, int32_t *bcol, double *vtop,
+               double *vbot, int32_t *fail, hipStream_t s)
+{
+    hipLaunchKernelGGL(bcsr_fill_kernel, dim3((nbr + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, rp, ci, va, nbr, browptr,
+                       bcol, vtop, vbot, fail);
+}
+
+// ---------------------------------------------------------------------------
 // B x for the short-and-wide constraint block (4 rows of ~n/2 entries): one
 // workgroup per (column window, row), 16-byte loads of the row's entries in the
 // window, x (optionally x .* scale) gathered; the last block of the grid sums the

@@ -59,6 +59,8 @@ void spk_ctx::ensure_vectors()
         ld = want;
         ws_restart = -1;
         tmp.release();
+        zun.release();   // every vector sized by ld goes with it (a second KSPSetOperators may bring a larger system)
+        tmpb.release();
         stage_x.release();
         stage_y.release();
         xsol.release();
@@ -71,21 +73,57 @@ void spk_ctx::ensure_vectors()
     if (!stage_y.p) stage_y.alloc((size_t)ld);
 }
 
+// Pageable host array -> device through two pinned staging buffers: host threads fill one while the other is on
+// the wire (a plain hipMemcpy of pageable memory runs far below the link: 0.35-0.55 s for the 461 MB of the
+// 1024^2 matrix in round 1, against ~10 ms of PCIe time).
+void spk_ctx::upload_staged(void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t kChunk = (size_t)32 << 20;
+    if (bytes == 0) return;
+    if (bytes < ((size_t)1 << 20)) {  // small arrays: not worth the pipeline
+        SPK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        SPK_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!pin[i]) SPK_HIP(hipHostMalloc(&pin[i], kChunk, hipHostMallocDefault));
+        if (!pin_ev[i]) SPK_HIP(hipEventCreateWithFlags(&pin_ev[i], hipEventDisableTiming));
+    }
+    int which = 0;
+    for (size_t off = 0; off < bytes; off += kChunk, which ^= 1) {
+        const size_t len = std::min(kChunk, bytes - off);
+        SPK_HIP(hipEventSynchronize(pin_ev[which]));  // the copy that last used this buffer has left it
+        char *stage = (char *)pin[which];
+        const char *from = (const char *)src + off;
+        parallel_for((int64_t)len, [&](int64_t b0, int64_t b1, int) { std::memcpy(stage + b0, from + b0, (size_t)(b1 - b0)); }, 16);
+        SPK_HIP(hipMemcpyAsync((char *)dst + off, stage, len, hipMemcpyHostToDevice, stream));
+        SPK_HIP(hipEventRecord(pin_ev[which], stream));
+    }
+}
+
 namespace spk {
 
 // ---------------------------------------------------------------------------
 // KSPSetOperators: upload one block (SaddlePointProblem.c:66; the nest at :45-60)
 // ---------------------------------------------------------------------------
+// host array -> fresh device buffer through the pinned staging pipeline (large arrays), pad zeroed
+template <class T>
+static void up(spk_ctx *c, DevBuf<T> &d, const T *h, size_t count, size_t pad)
+{
+    d.alloc_raw(count, pad);
+    c->upload_staged(d.p, h, count * sizeof(T));
+}
+
 template <class VR, class VI, class VD>
-static void upload_csr(CsrDev &D, int32_t nrows, int32_t ncols, const VR &rowptr, const VI &colidx, const VD &val,
+static void upload_csr(spk_ctx *c, CsrDev &D, int32_t nrows, int32_t ncols, const VR &rowptr, const VI &colidx, const VD &val,
                        bool tiles)
 {
     D.nrows = nrows;
     D.ncols = ncols;
     D.nnz = (int64_t)colidx.size();
-    D.rowptr.upload(rowptr.data(), rowptr.size(), 8);
-    D.colidx.upload(colidx.data(), colidx.size(), 16);
-    D.val.upload(val.data(), val.size(), 16);
+    up(c, D.rowptr, rowptr.data(), rowptr.size(), 8);
+    up(c, D.colidx, colidx.data(), colidx.size(), 16);
+    up(c, D.val, val.data(), val.size(), 16);
     if (tiles) {
         std::vector<int32_t> tr;
         k::build_tiles(rowptr.data(), nrows, tr);
@@ -115,9 +153,9 @@ static void agree_or_fail(spk_ctx *c, const Error *mine, const char *step)
 static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
                         const int32_t *rowptr, const int32_t *colidx, const double *val)
 {
-    SplitCsr sp;
+    std::vector<int32_t> garray;   // sorted global numbers of the off-rank columns (MatMPIAIJ's garray)
     Error local{0, ""};
-    try {  // ---- local part: validation, split, uploads (no collective inside)
+    try {  // ---- local part: validation, upload, split and blocking on the device (no collective inside)
     if (rowptr[0] != 0) fail(SPK_ERR_ARG, "A00: rowptr[0] must be 0");
     if (row_begin < 0 || row_begin + nrows_local > ncols_global)
         fail(SPK_ERR_ARG, "A00: rows [%lld,%lld) outside the %lld x %lld block", (long long)row_begin,
@@ -125,90 +163,152 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     for (int32_t r = 0; r < nrows_local; ++r)
         if (rowptr[r + 1] < rowptr[r]) fail(SPK_ERR_ARG, "A00: rowptr not monotone at row %d", r);
 
-    split_csr(row_begin, nrows_local, rowptr, colidx, val, sp, ncols_global);  // threaded, validates the columns
-    if (sp.bad_column) fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", sp.bad_value, (long long)ncols_global);
+    hipStream_t s = c->stream;
+    const int32_t n = nrows_local;
+    const int64_t nnz = rowptr[n];
+    const int64_t lo = row_begin, hi = row_begin + n;
+    // the caller's slab as it is, once
+    DevBuf<int32_t> rp_in, ci_in, cnt, orp, scratch, flags;
+    DevBuf<double> va_in;
+    rp_in.alloc_raw((size_t)n + 1, 8);
+    ci_in.alloc_raw((size_t)nnz, 16);
+    va_in.alloc_raw((size_t)nnz, 16);
+    c->upload_staged(rp_in.p, rowptr, sizeof(int32_t) * ((size_t)n + 1));
+    c->upload_staged(ci_in.p, colidx, sizeof(int32_t) * (size_t)nnz);
+    c->upload_staged(va_in.p, val, sizeof(double) * (size_t)nnz);
+    // off-rank entries per row (and the column range check), exclusive scan
+    cnt.alloc_raw((size_t)n, 8);
+    orp.alloc_raw((size_t)n + 1, 8);
+    scratch.alloc_raw((size_t)n / 2048 + 8);
+    flags.alloc(4);
+    k::csr_count_off(rp_in.p, ci_in.p, n, lo, hi, ncols_global, cnt.p, flags.p, s);
+    k::exclusive_scan_i32(cnt.p, n, orp.p, scratch.p, s);
+    int32_t hflags[4] = {0, 0, 0, 0}, noff = 0;
+    SPK_HIP(hipMemcpyAsync(hflags, flags.p, sizeof hflags, hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipMemcpyAsync(&noff, orp.p + n, sizeof noff, hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipStreamSynchronize(s));
+    if (hflags[0]) fail(SPK_ERR_ARG, "A00: column %d out of range [0,%lld)", hflags[1], (long long)ncols_global);
     // validation passed: from here on the previous operator is being replaced (a refused block, above,
     // leaves it in place and usable)
     c->have_A = false;
     c->pc_ready = false;
+    if (c->n_global != ncols_global || c->row_begin != row_begin || c->n_local != nrows_local) {
+        // another row range: a constraint block set before belongs to the old one (its column slice and every
+        // array sized by it); KSPSetOperators has to bring the new A10 as well
+        c->have_B = false;
+        c->m = 0;
+        c->b_general = false;
+        c->m_wide = 0;
+        c->bd.release();
+        c->bdpk.release();
+    }
     c->n_global = ncols_global;
     c->row_begin = row_begin;
     c->n_local = nrows_local;
-    c->n_ghost = (int32_t)sp.garray.size();
-    upload_csr(c->Ad, nrows_local, nrows_local, sp.d_rowptr, sp.d_colidx, sp.d_val, true);
+    const int64_t nnzd = nnz - noff;
+    CsrDev &Ad = c->Ad;
+    Ad.nrows = n;
+    Ad.ncols = n;
+    Ad.nnz = nnzd;
+    Ad.rowptr.alloc_raw((size_t)n + 1, 8);
+    Ad.colidx.alloc_raw((size_t)nnzd, 16);
+    Ad.val.alloc_raw((size_t)nnzd, 16);
+    c->Ao.nrows = 0;
+    c->Ao.ncols = 0;
+    c->Ao.nnz = noff;
+    c->Ao.colidx.alloc_raw((size_t)noff, 16);
+    c->Ao.val.alloc_raw((size_t)noff, 16);
+    k::csr_split(rp_in.p, ci_in.p, va_in.p, n, lo, hi, orp.p, Ad.rowptr.p, Ad.colidx.p, Ad.val.p, c->Ao.colidx.p, c->Ao.val.p, s);
+    // what the host still needs: the diagonal block's row pointers (tile tables are a greedy scan of them) and the
+    // few off-rank entries (ghost numbering, halo plan)
+    HostBuf<int32_t> drp;
+    drp.alloc((size_t)n + 1);
+    std::vector<int32_t> orp_h, ocol_h((size_t)noff);
+    if (noff > 0) {
+        orp_h.resize((size_t)n + 1);
+        SPK_HIP(hipMemcpyAsync(orp_h.data(), orp.p, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipMemcpyAsync(ocol_h.data(), c->Ao.colidx.p, sizeof(int32_t) * (size_t)noff, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        parallel_for((int64_t)n + 1, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t r = r0; r < r1; ++r) drp[(size_t)r] = rowptr[r] - orp_h[(size_t)r];
+        });
+    } else {
+        parallel_for((int64_t)n + 1, [&](int64_t r0, int64_t r1, int) {
+            for (int64_t r = r0; r < r1; ++r) drp[(size_t)r] = rowptr[r];
+        });
+    }
+    {
+        std::vector<int32_t> tr;
+        k::build_tiles(drp.data(), n, tr);
+        Ad.ntiles = (int32_t)tr.size() - 1;
+        Ad.tile_row.upload(tr.data(), tr.size(), 8);
+    }
+    // ghost numbering: sorted unique global columns, off-rank column indices rewritten to ghost numbers
+    garray.assign(ocol_h.begin(), ocol_h.end());
+    std::sort(garray.begin(), garray.end());
+    garray.erase(std::unique(garray.begin(), garray.end()), garray.end());
+    c->n_ghost = (int32_t)garray.size();
+    if (noff > 0) {
+        for (auto &g : ocol_h) g = (int32_t)(std::lower_bound(garray.begin(), garray.end(), g) - garray.begin());
+        SPK_HIP(hipMemcpyAsync(c->Ao.colidx.p, ocol_h.data(), sizeof(int32_t) * (size_t)noff, hipMemcpyHostToDevice, s));
+        SPK_HIP(hipStreamSynchronize(s));
+    }
+    // off-rank block: compressed to the rows that have entries (FP32 sweeps), and over all rows (SpMV epilogue)
+    {
+        std::vector<int32_t> rows, corp(1, 0);
+        if (noff > 0)
+            for (int32_t r = 0; r < n; ++r)
+                if (orp_h[(size_t)r + 1] > orp_h[(size_t)r]) {
+                    rows.push_back(r);
+                    corp.push_back(orp_h[(size_t)r + 1]);
+                }
+        c->Ao.nrows = (int32_t)rows.size();
+        c->Ao.ncols = c->n_ghost;
+        c->Ao.rowptr.upload(corp.data(), corp.size(), 8);
+        c->ao_rows.upload(rows.data(), rows.size(), 8);
+        c->ao_rowptr_full.release();
+        if (c->n_ghost > 0) std::swap(c->ao_rowptr_full.p, orp.p), std::swap(c->ao_rowptr_full.n, orp.n);
+    }
 
-    // 2x2-blocked copy when every row pair shares its pattern and columns pair up (dof-2 grids).
-    // Block row br then starts at block rp[2 br] / 4, so one threaded pass verifies and fills.
+    // 2x2-blocked copy when every row pair shares its pattern and columns pair up (dof-2 grids): verified
+    // and filled by one kernel, block row br starting at block rowptr[2 br] / 4
     {
         BcsrDev &Ab = c->Ab;
         Ab.ok = false;
         Ab.nbrows = 0;
         Ab.ntiles = 0;
-        const auto &rp = sp.d_rowptr;
-        const auto &ci = sp.d_colidx;
-        const int64_t nnzd = rp[(size_t)nrows_local];
-        bool ok = nrows_local % 2 == 0 && nrows_local > 0 && nnzd % 4 == 0;
-        HostBuf<int32_t> brp, bcol;
-        HostBuf<double> vt, vb;
-        if (ok) {
-            const int32_t nbr = nrows_local / 2;
-            brp.alloc((size_t)nbr + 1);
-            bcol.alloc((size_t)(nnzd / 4));
-            vt.alloc((size_t)(nnzd / 2));
-            vb.alloc((size_t)(nnzd / 2));
-            std::vector<int> fail_t(64, 0);
-            parallel_for(nbr, [&](int64_t b0, int64_t b1, int t) {
-                for (int64_t br = b0; br < b1; ++br) {
-                    const int32_t r = (int32_t)(2 * br);
-                    const int32_t k0 = rp[(size_t)r], k1 = rp[(size_t)r + 1], l0 = k1, l1 = rp[(size_t)r + 2];
-                    if ((k1 - k0) != (l1 - l0) || ((k1 - k0) & 1) || (k0 & 3)) { fail_t[(size_t)t] = 1; return; }
-                    brp[(size_t)br] = k0 / 4;
-                    int64_t q = k0 / 4;
-                    for (int32_t k = 0; k < k1 - k0; k += 2, ++q) {
-                        const int32_t c0 = ci[(size_t)(k0 + k)], c1 = ci[(size_t)(k0 + k + 1)];
-                        if ((c0 & 1) || c1 != c0 + 1 || ci[(size_t)(l0 + k)] != c0 || ci[(size_t)(l0 + k + 1)] != c1) {
-                            fail_t[(size_t)t] = 1;
-                            return;
-                        }
-                        bcol[(size_t)q] = c0 >> 1;
-                        vt[(size_t)(2 * q)] = sp.d_val[(size_t)(k0 + k)];
-                        vt[(size_t)(2 * q + 1)] = sp.d_val[(size_t)(k0 + k + 1)];
-                        vb[(size_t)(2 * q)] = sp.d_val[(size_t)(l0 + k)];
-                        vb[(size_t)(2 * q + 1)] = sp.d_val[(size_t)(l0 + k + 1)];
-                    }
-                }
-            });
-            for (int f : fail_t) ok = ok && !f;
-            if (ok) brp[(size_t)nbr] = (int32_t)(nnzd / 4);
-        }
-        if (ok) {
-            Ab.nbrows = nrows_local / 2;
-            Ab.nblocks = (int64_t)bcol.size();
-            Ab.browptr.upload(brp.data(), brp.size(), 8);
-            Ab.bcol.upload(bcol.data(), bcol.size(), 16);
-            Ab.vtop.upload(vt.data(), vt.size(), 32);
-            Ab.vbot.upload(vb.data(), vb.size(), 32);
-            std::vector<int32_t> tb;
-            k::build_btiles(brp.data(), Ab.nbrows, tb);
-            Ab.long_rows = false;
-            for (int32_t br = 0; br < Ab.nbrows && !Ab.long_rows; ++br) Ab.long_rows = brp[(size_t)br + 1] - brp[(size_t)br] > k::kBTile;
-            Ab.ntiles = (int32_t)tb.size() - 1;
-            Ab.tile_brow.upload(tb.data(), tb.size(), 8);
-            Ab.ok = true;
+        Ab.long_rows = false;
+        if (n % 2 == 0 && n > 0 && nnzd % 4 == 0) {
+            const int32_t nbr = n / 2;
+            Ab.browptr.alloc_raw((size_t)nbr + 1, 8);
+            Ab.bcol.alloc_raw((size_t)(nnzd / 4), 16);
+            Ab.vtop.alloc_raw((size_t)(nnzd / 2), 32);
+            Ab.vbot.alloc_raw((size_t)(nnzd / 2), 32);
+            SPK_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t) * 4, s));
+            k::bcsr_fill(Ad.rowptr.p, Ad.colidx.p, Ad.val.p, nbr, Ab.browptr.p, Ab.bcol.p, Ab.vtop.p, Ab.vbot.p, flags.p, s);
+            SPK_HIP(hipMemcpyAsync(hflags, flags.p, sizeof hflags, hipMemcpyDeviceToHost, s));
+            SPK_HIP(hipStreamSynchronize(s));
+            if (!hflags[0]) {
+                HostBuf<int32_t> brp;
+                brp.alloc((size_t)nbr + 1);
+                parallel_for((int64_t)nbr + 1, [&](int64_t b0, int64_t b1, int) {
+                    for (int64_t br = b0; br < b1; ++br) brp[(size_t)br] = drp[(size_t)(2 * br)] / 4;
+                });
+                Ab.nbrows = nbr;
+                Ab.nblocks = nnzd / 4;
+                std::vector<int32_t> tb;
+                k::build_btiles(brp.data(), Ab.nbrows, tb);
+                for (int32_t br = 0; br < Ab.nbrows && !Ab.long_rows; ++br) Ab.long_rows = brp[(size_t)br + 1] - brp[(size_t)br] > k::kBTile;
+                Ab.ntiles = (int32_t)tb.size() - 1;
+                Ab.tile_brow.upload(tb.data(), tb.size(), 8);
+                Ab.ok = true;
+            } else {
+                Ab.browptr.release(); Ab.bcol.release(); Ab.vtop.release(); Ab.vbot.release();
+            }
         }
         const char *fmt = getenv("SPK_SPMV_FORMAT");
         c->spmv_format = (Ab.ok && !(fmt && !strcmp(fmt, "csr"))) ? 1 : 0;
     }
-
-    // compress the off-rank block to the rows that have entries
-    std::vector<int32_t> rows, orp(1, 0);
-    for (int32_t r = 0; r < nrows_local; ++r)
-        if (sp.o_rowptr[(size_t)r + 1] > sp.o_rowptr[(size_t)r]) {
-            rows.push_back(r);
-            orp.push_back(sp.o_rowptr[(size_t)r + 1]);
-        }
-    upload_csr(c->Ao, (int32_t)rows.size(), c->n_ghost, orp, sp.o_colidx, sp.o_val, false);
-    c->ao_rows.upload(rows.data(), rows.size(), 8);
     } catch (const Error &e) {
         local = e;
     } catch (const std::exception &e) {
@@ -228,13 +328,13 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
         for (int r = 1; r < P; ++r)
             if (all[2 * r] != all[2 * r - 1]) fail(SPK_ERR_ARG, "A00: row slabs must tile [0,n) in rank order");
         std::vector<std::vector<char>> ghosts;
-        c->comm->host_allgatherv(sp.garray.data(), sp.garray.size() * sizeof(int32_t), ghosts);
+        c->comm->host_allgatherv(garray.data(), garray.size() * sizeof(int32_t), ghosts);
         for (int p = 0; p < P; ++p) {
             if (p == me) continue;
             // what I receive from p: my ghosts inside p's range (contiguous in sorted garray)
             const int64_t plo = all[2 * p], phi = all[2 * p + 1];
             int64_t nrecv = 0;
-            for (int32_t g : sp.garray) nrecv += (g >= plo && g < phi);
+            for (int32_t g : garray) nrecv += (g >= plo && g < phi);
             // what I send to p: p's ghosts inside my range, in p's order
             const int32_t *pg = (const int32_t *)ghosts[(size_t)p].data();
             const size_t npg = ghosts[(size_t)p].size() / sizeof(int32_t);
@@ -257,9 +357,7 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     if (P > 1 && c->recv_off.back() != c->n_ghost) fail(SPK_ERR_ARG, "A00: ghost columns not owned by any rank");
     c->send_idx.upload(send_idx.data(), send_idx.size(), 8);
     c->send_buf.alloc(send_idx.size(), 8);
-    // off-rank part in "SpMV epilogue" form: row pointers over all local rows
-    c->ao_rowptr_full.release();
-    if (c->n_ghost > 0) c->ao_rowptr_full.upload(sp.o_rowptr.data(), sp.o_rowptr.size(), 8);
+    // (the off-rank part in "SpMV epilogue" form -- row pointers over all local rows -- is the scan result kept above)
     // halo rows as contiguous ranges (slab partitions): lets the producer of z fill send_buf itself
     c->send_ranges = k::SendRanges{};
     {
@@ -303,19 +401,37 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
     const int32_t nl = c->n_local;
     const int64_t lo = c->row_begin, hi = lo + nl;
     // local column numbers, ascending inside each row
-    std::vector<int32_t> col((size_t)rowptr[m]);
-    std::vector<double> v((size_t)rowptr[m]);
-    for (int32_t r = 0; r < m; ++r) {
-        const int32_t k0 = rowptr[r], k1 = rowptr[r + 1];
-        std::vector<int32_t> perm((size_t)(k1 - k0));
-        std::iota(perm.begin(), perm.end(), k0);
-        if (!std::is_sorted(colidx + k0, colidx + k1))  // PETSc rows come sorted: no work then
-            std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return colidx[a] < colidx[b]; });
-        for (int32_t i = 0; i < k1 - k0; ++i) {
-            const int32_t g = colidx[perm[(size_t)i]];
-            if (g < lo || g >= hi) fail(SPK_ERR_ARG, "A10: column %d not owned by this rank [%lld,%lld)", g, (long long)lo, (long long)hi);
-            col[(size_t)(k0 + i)] = (int32_t)(g - lo);
-            v[(size_t)(k0 + i)] = val[perm[(size_t)i]];
+    // (threaded over the entries: the reference's 4 rows hold ~n/2 entries each -- 4 M at 1024^2)
+    HostBuf<int32_t> col;
+    HostBuf<double> v;
+    col.alloc((size_t)rowptr[m]);
+    v.alloc((size_t)rowptr[m]);
+    {
+        std::vector<int32_t> badcol(64, -1);
+        parallel_for(rowptr[m], [&](int64_t a, int64_t b, int t) {
+            for (int64_t k = a; k < b; ++k) {
+                const int32_t g = colidx[k];
+                if (g < lo || g >= hi) badcol[(size_t)t] = g;
+                col[(size_t)k] = (int32_t)(g - lo);
+                v[(size_t)k] = val[k];
+            }
+        });
+        for (int32_t g : badcol)
+            if (g != -1) fail(SPK_ERR_ARG, "A10: column %d not owned by this rank [%lld,%lld)", g, (long long)lo, (long long)hi);
+        for (int32_t r = 0; r < m; ++r) {   // PETSc rows come sorted: nothing to do then
+            const int32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+            if (std::is_sorted(col.data() + k0, col.data() + k1)) continue;
+            std::vector<int32_t> perm((size_t)(k1 - k0));
+            std::iota(perm.begin(), perm.end(), 0);
+            std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return col[(size_t)(k0 + a)] < col[(size_t)(k0 + b)]; });
+            std::vector<int32_t> c2((size_t)(k1 - k0));
+            std::vector<double> v2((size_t)(k1 - k0));
+            for (int32_t i = 0; i < k1 - k0; ++i) {
+                c2[(size_t)i] = col[(size_t)(k0 + perm[(size_t)i])];
+                v2[(size_t)i] = v[(size_t)(k0 + perm[(size_t)i])];
+            }
+            std::copy(c2.begin(), c2.end(), col.data() + k0);
+            std::copy(v2.begin(), v2.end(), v.data() + k0);
         }
     }
     // Which rows go through the column-window (long-row) kernel: all of them for m <= 8 (the reference's 4
@@ -346,28 +462,36 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
     WideDev &B = c->B;
     B.m = mw;
     B.ncols = nl;
-    std::vector<int32_t> wcol, wrp(1, 0);
-    std::vector<double> wv;
-    for (int32_t r : wide) {
-        wcol.insert(wcol.end(), col.begin() + rowptr[r], col.begin() + rowptr[r + 1]);
-        wv.insert(wv.end(), v.begin() + rowptr[r], v.begin() + rowptr[r + 1]);
-        wrp.push_back((int32_t)wcol.size());
+    std::vector<int32_t> wcol_own, wrp(1, 0);
+    std::vector<double> wv_own;
+    const int32_t *wcol = col.data();
+    const double *wv = v.data();
+    if (!c->b_general) {  // every row, in order: the arrays as they are
+        for (int32_t r = 0; r < m; ++r) wrp.push_back(rowptr[r + 1]);
+    } else {
+        for (int32_t r : wide) {
+            wcol_own.insert(wcol_own.end(), col.data() + rowptr[r], col.data() + rowptr[r + 1]);
+            wv_own.insert(wv_own.end(), v.data() + rowptr[r], v.data() + rowptr[r + 1]);
+            wrp.push_back((int32_t)wcol_own.size());
+        }
+        wcol = wcol_own.data();
+        wv = wv_own.data();
     }
-    B.nnz = (int64_t)wcol.size();
+    B.nnz = wrp.back();
     int32_t win = 8192;
     while ((int64_t)(nl + win - 1) / win > k::kMaxBlocks) win *= 2;
     B.win = win;
     B.nwin = mw > 0 ? (nl + win - 1) / win : 0;
     std::vector<int32_t> winptr((size_t)(B.nwin + 1) * (size_t)std::max(mw, 1));
     for (int32_t r = 0; r < mw; ++r) {
-        const int32_t *b = wcol.data() + wrp[(size_t)r], *e = wcol.data() + wrp[(size_t)r + 1];
+        const int32_t *b = wcol + wrp[(size_t)r], *e = wcol + wrp[(size_t)r + 1];
         for (int32_t w = 0; w <= B.nwin; ++w) {
             const int64_t c0 = (int64_t)w * win;
             winptr[(size_t)w * mw + r] = wrp[(size_t)r] + (int32_t)(std::lower_bound(b, e, (int32_t)std::min<int64_t>(c0, nl)) - b);
         }
     }
-    B.colidx.upload(wcol.data(), wcol.size(), 16);
-    B.val.upload(wv.data(), wv.size(), 16);
+    up(c, B.colidx, wcol, (size_t)B.nnz, 16);
+    up(c, B.val, wv, (size_t)B.nnz, 16);
     B.winptr.upload(winptr.data(), winptr.size(), 8);
     // the general block by rows (its long rows left empty: the window kernel fills their results in)
     c->Bc.rowptr.release(); c->Bc.colidx.release(); c->Bc.val.release(); c->Bc.tile_row.release();
@@ -380,29 +504,51 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
         std::vector<double> cv;
         for (int32_t r = 0; r < m; ++r) {
             if (!is_wide[(size_t)r]) {
-                cci.insert(cci.end(), col.begin() + rowptr[r], col.begin() + rowptr[r + 1]);
-                cv.insert(cv.end(), v.begin() + rowptr[r], v.begin() + rowptr[r + 1]);
+                cci.insert(cci.end(), col.data() + rowptr[r], col.data() + rowptr[r + 1]);
+                cv.insert(cv.end(), v.data() + rowptr[r], v.data() + rowptr[r + 1]);
             }
             crp[(size_t)r + 1] = (int32_t)cci.size();
         }
-        upload_csr(c->Bc, m, nl, crp, cci, cv, true);
+        upload_csr(c, c->Bc, m, nl, crp, cci, cv, true);
     }
     if ((size_t)m + 64 > c->y1tmp.n) c->y1tmp.alloc((size_t)m + 64);
     if ((size_t)m + 64 > c->ttmp.n) c->ttmp.alloc((size_t)m + 64);
 
     // B^T by rows (n_local x m), entries of a row ordered by constraint index
+    // (threads own disjoint column ranges and walk the sorted rows' entries inside them: counts, then fill in
+    // row order -- the same arrays as a sequential counting sort)
     std::vector<int32_t> trp((size_t)nl + 1, 0), tci((size_t)rowptr[m]);
     std::vector<double> tv((size_t)rowptr[m]);
-    for (int64_t k = 0; k < rowptr[m]; ++k) trp[(size_t)col[(size_t)k] + 1]++;
-    for (int32_t i = 0; i < nl; ++i) trp[(size_t)i + 1] += trp[(size_t)i];
-    std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
-    for (int32_t r = 0; r < m; ++r)
-        for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-            const int32_t p = fill[(size_t)col[(size_t)k]]++;
-            tci[(size_t)p] = r;
-            tv[(size_t)p] = v[(size_t)k];
+    auto row_range = [&](int32_t r, int64_t c0, int64_t c1, int32_t &b, int32_t &e) {
+        const int32_t *rb = col.data() + rowptr[r], *re = col.data() + rowptr[r + 1];
+        b = rowptr[r] + (int32_t)(std::lower_bound(rb, re, (int32_t)c0) - rb);
+        e = rowptr[r] + (int32_t)(std::lower_bound(rb, re, (int32_t)c1) - rb);
+    };
+    parallel_for(nl, [&](int64_t c0, int64_t c1, int) {
+        for (int32_t r = 0; r < m; ++r) {
+            int32_t b, e;
+            row_range(r, c0, c1, b, e);
+            for (int32_t k = b; k < e; ++k) trp[(size_t)col[(size_t)k] + 1]++;
         }
-    upload_csr(c->Bt, nl, m, trp, tci, tv, false);
+    });
+    for (int32_t i = 0; i < nl; ++i) trp[(size_t)i + 1] += trp[(size_t)i];
+    {
+        HostBuf<int32_t> fill;
+        fill.alloc((size_t)nl + 1);
+        parallel_for(nl, [&](int64_t c0, int64_t c1, int) {
+            for (int64_t i = c0; i < c1; ++i) fill[(size_t)i] = trp[(size_t)i];
+            for (int32_t r = 0; r < m; ++r) {
+                int32_t b, e;
+                row_range(r, c0, c1, b, e);
+                for (int32_t k = b; k < e; ++k) {
+                    const int32_t p = fill[(size_t)col[(size_t)k]]++;
+                    tci[(size_t)p] = r;
+                    tv[(size_t)p] = v[(size_t)k];
+                }
+            }
+        });
+    }
+    upload_csr(c, c->Bt, nl, m, trp, tci, tv, false);
     c->m = m;
     c->have_B = m > 0;
     c->pc_ready = false;
@@ -772,7 +918,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // 56.4 us (two: the fused SpMV + MDot kernel is a chain of latencies at <= 4 workgroups per CU);
     // 256^2 36.2 / 30.0 / 40.1, 512^2 71.8 / 68.1 / 81.0; the full 1024^2 grid 215 / 218 / 236 (four stays)
     const bool three = two && form != SPK_ITER_TWO_LAUNCH;
-    if (two && !c->zun.p) c->zun.alloc((size_t)ld);
+    if (two && c->zun.n < (size_t)ld) c->zun.alloc((size_t)ld);
     const int lam_in_dot = c->comm->rank() == 0 ? 1 : 0;
 
     c->ka.tentative = single ? 1 : 0;
