@@ -97,3 +97,14 @@ def test_rectangular_grid_and_no_bc(oracle):
         t[c::2] = 1.0
         assert np.abs(S @ t).max() < 1e-12
     assert f.sum() == pytest.approx(3.0, rel=1e-11)      # integral of (1,2) over the unit square
+
+
+def test_input_fixture_is_derived_not_transcribed():
+    """tests/golden/appendix_b.json is the output of an independent exact derivation (sympy on the
+    reference's element formulas + a numpy/scipy assembly), re-run here and compared."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "golden", "derive_appendix_b.py"), "--check"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "matches a fresh derivation" in out.stdout
