@@ -105,7 +105,21 @@ static PetscErrorCode SpkGlueCreate(MPI_Comm comm, Mat A, Mat B, SpkGlue **out)
     ierr = PetscNew(&g); CHKERRQ(ierr);
     ierr = MPI_Comm_rank(comm, &rank); CHKERRQ(ierr);
     ierr = MPI_Comm_size(comm, &size); CHKERRQ(ierr);
-    if (spk_create(&g->ctx, 0 /* one visible GPU per rank */)) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "libspk: %s", spk_last_error(NULL));
+    {
+        /* Which GPU this rank drives: -spk_device <d> when given; otherwise the rank's position among the
+         * ranks of its node (MPI_COMM_TYPE_SHARED) -- one process per GPU, as the bench launches them.  A
+         * launcher that already restricts visibility (ROCR_VISIBLE_DEVICES=<local rank>) passes -spk_device 0. */
+        MPI_Comm node;
+        PetscMPIInt local = 0;
+        PetscInt dev = -1;
+        PetscBool given = PETSC_FALSE;
+        ierr = MPI_Comm_split_type(comm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node); CHKERRQ(ierr);
+        ierr = MPI_Comm_rank(node, &local); CHKERRQ(ierr);
+        ierr = MPI_Comm_free(&node); CHKERRQ(ierr);
+        ierr = PetscOptionsGetInt(NULL, NULL, "-spk_device", &dev, &given); CHKERRQ(ierr);
+        if (!given) dev = (PetscInt)local;
+        if (spk_create(&g->ctx, (int)dev)) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "libspk (device %d): %s", (int)dev, spk_last_error(NULL));
+    }
     if (size > 1) {
         if (!rank && spk_comm_unique_id(id)) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "libspk: %s", spk_last_error(NULL));
         ierr = MPI_Bcast(id, 128, MPI_BYTE, 0, comm); CHKERRQ(ierr);
