@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--inner-sweeps", type=int, default=0, help="FP32 damped-Jacobi Richardson sweeps standing for "
                                                                 "diag(A)^-1 in the PC (BASELINE config 5's mixed FP32 inner solve)")
     ap.add_argument("--inner-omega", type=float, default=0.8)
-    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="opts.iteration_form: 0 auto, 1 four launches per iteration, 2 two launches, 3 three launches")
     ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
     args = ap.parse_args()

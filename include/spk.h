@@ -112,10 +112,13 @@ typedef struct spk_opts {
                                folded in), MAXPY with the norm and the next iteration's preconditioner + B^T
                                product on the un-normalised vector (B D w' by linearity from B D w).  Needs
                                the 2x2-blocked matrix layout and restart + m <= 62; otherwise four launches;
-                               SPK_ITER_THREE_LAUNCH (3): as 2 with VecMDot (h and B D w) as a launch of its own. */
+                               SPK_ITER_THREE_LAUNCH (3): as 2 with VecMDot (h and B D w) as a launch of its own;
+                               SPK_ITER_BA (4, single rank, small systems): VecMAXPY + norm + next PCApply AND the next
+                               MatMult in one launch behind neighbour flags, un-normalised basis with one scale factor
+                               per vector (two launches per iteration; measured no faster than 3: bandwidth-bound). */
     int32_t reserved;
 } spk_opts;
-enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3 };
+enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3, SPK_ITER_BA = 4 };
 
 typedef struct spk_result {
     int32_t its;            /* KSPGetIterationNumber   */

@@ -104,9 +104,15 @@ struct BcsrDev {
     DevBuf<int32_t> browptr, bcol;
     DevBuf<double> vtop, vbot;  // (a00,a01) and (a10,a11) per block
     DevBuf<int32_t> tile_brow;
+    DevBuf<int32_t> tile_desc;  // per tile {first block row, end block row, first block, end block} (one load instead of a chain)
     int32_t ntiles = 0;
     bool ok = false;
     bool long_rows = false;  // a block row longer than one tile exists (the two-launch iteration does not take those)
+    // "BA" iteration kernel (MAXPY + next SpMV in one launch, neighbour flags): workgroup rho (row order) owns
+    // ba_tb consecutive tiles; ba_nbr[2 rho], [2 rho + 1] = first / last workgroup whose rows its columns touch
+    bool ba_ok = false;
+    int32_t ba_slots = 0, ba_tb = 0, ba_chunk = 0;
+    DevBuf<int32_t> ba_nbr, ba_wt;   // ba_wt[2 rho], [2 rho + 1] = its tiles [t0, t1)
 };
 
 // Short-and-wide block (B: m rows x n_local cols) cut into column windows so
@@ -425,6 +431,7 @@ struct IterA {
     const int32_t *browptr, *bcol;
     const double *vtop, *vbot;
     const int32_t *tile_brow;
+    const int4 *tdesc;
     int ntiles, tiles_per_xcd, slots;  // slots: workgroups per XCD (iter_slots)
     OffDiag od;
     // vectors
@@ -483,10 +490,56 @@ struct IterB {
 };
 // dots = false: the SpMV / normalisation part alone (three-launch form; one tile per workgroup: slots = tiles_per_xcd)
 void iter_spmv_mdot(const IterA &a, hipStream_t s, bool dots = true);
+// BA: w' = s_w w~ - V~ (h .* sc) with ||w'||^2, z~ = M^-1 w', then -- behind neighbour flags instead of a kernel
+// boundary -- the NEXT product w~ = A z~ + B^T y~ of the same row tiles; Givens of this iteration in the reducer.
+// The basis stays UN-normalised (V~_i, Z~_i) with one scale factor per vector (sc[i] = 1 / ||w'_i||).
+struct IterBA {
+    const int32_t *browptr, *bcol;
+    const double *vtop, *vbot;
+    const int32_t *tile_brow;
+    const int32_t *tdesc;  // per tile {first block row, end block row, first block, end block}
+    int ntiles, tiles_per_xcd, slots, tb;
+    int chunk;             // double2 entries per workgroup in phase B (<= 256)
+    const int32_t *nbr, *wt;   // wt: per workgroup {t0, t1, first owner, last owner to wait for}
+    uint32_t *flags;
+    uint32_t seq;
+    const double *V;       // basis, un-normalised from vector 1 on
+    int64_t ldv;
+    int nv;                // loc + 1
+    const double *dots;    // reduced RAW [V~_i . w~ (nv), B D w~ (m)]
+    double *sc;            // scale factors, (restart + 2)
+    double *tb_;           // B D V~_i per basis vector, (restart + 2) x 8
+    double *w;             // V_{loc+1}: in w~, out w'
+    const double *dinv, *bd;
+    int64_t ldb;
+    const double *shat, *gram;
+    int fact;
+    int64_t nl;
+    int m, packed;
+    double *zout;          // Z_{loc+1} = z~ (gathered by the SpMV phase of this launch)
+    double *wnext;         // V_{loc+2} = w~ of the next iteration
+    const double *wl_in;
+    double *wl_out;
+    double *hbuf;          // scaled Hessenberg column of this iteration (nv values)
+    int lam_in_dot, last;  // last: no SpMV phase (last iteration of a restart cycle)
+    double *partials, *nrm_out;
+    PeerAR ar;
+    int32_t *err;
+    uint32_t fin_ticks;
+    KrylovArrays ka;
+    int loc;
+    const int32_t *done;
+    unsigned long long *dbg;  // SPK_BA_DEBUG: 100 MHz time stamps of workgroup dbg_wg (nullptr: off)
+    int dbg_wg;
+};
+void iter_ba(const IterBA &p, hipStream_t s);
+// block-column range of every tile of the blocked matrix (set-up of the BA kernel's neighbour lists)
+void tile_col_range(const int32_t *browptr, const int32_t *bcol, const int32_t *tile_brow, int ntiles, int32_t *out, hipStream_t s);
 void iter_maxpy_uhead(IterB b, hipStream_t s);
 int iter_slots(int tiles_per_xcd, int wg_per_cu);
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0);
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0,
+                        double *sc = nullptr);
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
 // head of a fused Schur iteration: VecScale + PCApply + B^T part of MatMult in one pass, plus the
 // previous iteration's Givens step in workgroup 0 (loc_prev < 0: none)
@@ -501,7 +554,7 @@ void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double
                 int64_t nl, int m, double *z, double *c, double *w1side, const double *wl_in, double *wl_out,
                 const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *sr = nullptr,
                 int bd_packed = 0);
-void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s);
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc = nullptr);  // sc: y_i *= sc[i] (un-normalised Z)
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)
 void krylov_refine_decide(const KrylovArrays &ka, int loc, int mode, const double *dots, const double *nrm2,
@@ -583,6 +636,9 @@ struct spk_ctx {
     int ws_restart = -1;
     spk::DevBuf<double> V, Z, xsol, rhs, tmp;
     spk::DevBuf<double> zun;    // z~ of the two-launch iteration (un-normalised M^-1 w')
+    spk::DevBuf<uint32_t> ba_flags;  // BA kernel: one 128-byte line per workgroup
+    spk::DevBuf<double> ba_sc;       // scale factors of the un-normalised basis
+    uint32_t ba_seq = 0;
     spk::DevBuf<double> kry_d;  // H, cc, ss, rs, nrs, hcol, hist
     spk::DevBuf<spk::KrylovState> kst;
     spk::k::KrylovArrays ka{};

@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(1024) void mdot_ws16_kernel(const double *__restric
                                                          double *__restrict__ partials, int with_ww, double *__restrict__ out,
                                                          PeerAR ar, int split, FinErr fe, const int32_t *__restrict__ done)
 {
-    if (done && *done) return;
+    // the gate word is REQUESTED first and looked at behind the first tile's loads: a launch of these small forms is
+    // a chain of a few memory round trips (~1.3 us each under load), and "read done, then start" was one of them
+    const int32_t dn = done ? __builtin_nontemporal_load(done) : 0;
     __shared__ double lds[1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = (nv + 15) >> 4;
@@ -1084,6 +1086,7 @@ __global__ __launch_bounds__(1024) void mdot_ws16_kernel(const double *__restric
 #pragma unroll
                 for (int u = 0; u < U; ++u) a[v][u] = ld2s<NT>(Vi, (live && idx[u] >= 0) ? idx[u] : 0);
             }
+            if (dn) return;  // (uniform; every workgroup of the launch sees the same word)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (idx[u] < 0 || 2 * idx[u] >= n_dot) wv[u].x = 0.0;
@@ -1113,6 +1116,7 @@ __global__ __launch_bounds__(1024) void mdot_ws16_kernel(const double *__restric
             }
         }
     }
+    if (dn) return;
     double *row = partials + (size_t)blockIdx.x * kPartialLd;
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
@@ -2130,10 +2134,11 @@ void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2
     hipLaunchKernelGGL(krylov_init_kernel, dim3(1), dim3(64), 0, s, ka, o, bnorm2);
 }
 
-__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, double *tb, int m)
+__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, double *tb, int m, double *sc)
 {
     if (threadIdx.x != 0) return;
     KrylovState *st = ka.st;
+    if (sc) sc[0] = 1.0;  // v_0 is normalised; later basis vectors carry their own scale (BA iteration)
     st->loc_done = 0;
     st->skip_iter = st->done;  // a cycle ended early by the recurrence starts afresh here
     if (st->done) return;
@@ -2167,9 +2172,9 @@ __global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, d
     if (tb)  // B D v_0 for the single-reduction recurrence
         for (int r = 0; r < m; ++r) tb[r] = nrm2[1 + r] / rnorm;
 }
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb, int m)
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb, int m, double *sc)
 {
-    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, tb, m);
+    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, tb, m, sc);
 }
 
 // One Arnoldi step's scalar work (KSPFGMRESUpdateHessenberg + KSPConvergedDefault), run by a
@@ -2719,7 +2724,7 @@ __device__ __forceinline__ double inv_norm(double nrm2)
 template <int VW, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
 {
-    if (*a.done) return;
+    const int32_t dn = __builtin_nontemporal_load(a.done);  // looked at behind the first loads (see mdot_ws16_kernel)
     __shared__ double prod[kBTile * 4];
     __shared__ double wt[kThreads], vt[kThreads];
     const double scale = a.nrm2 ? inv_norm(a.nrm2[0]) : 1.0;
@@ -2731,6 +2736,7 @@ __global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
     const int bid = VW > 0 ? (int)blockIdx.x : (int)blockIdx.x - 1;
     if ((int)blockIdx.x == scalar_wg) {
         // ---- the scalar / reducing workgroup
+        if (dn) return;
         double *lamw = wt;
         if ((int)threadIdx.x < m) {
             const int r = threadIdx.x;
@@ -2789,8 +2795,11 @@ __global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
     for (int tl = slot; tl < a.tiles_per_xcd; tl += a.slots) {
         const int t = xcd * a.tiles_per_xcd + tl;
         if (t >= a.ntiles) break;
-        const int br0 = a.tile_brow[t], br1 = a.tile_brow[t + 1];
-        const int b0 = a.browptr[br0], b1 = a.browptr[br1];
+        // one descriptor per tile {first block row, end block row, first block, end block}: one round trip where
+        // tile_brow -> browptr was two
+        const int4 td = a.tdesc[t];
+        const int br0 = td.x, br1 = td.y;
+        const int b0 = td.z, b1 = td.w;
         const int cntb = b1 - b0;
         const int nr = 2 * (br1 - br0), r0 = 2 * br0;
         const int lr = threadIdx.x;
@@ -2843,6 +2852,7 @@ __global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
                 }
             }
         }
+        if (dn) return;  // (uniform over the launch)
         // phase 1: gather x 16 bytes at a time behind the block columns, products to LDS
 #pragma unroll
         for (int i = 0; i < kSteps; ++i) {
@@ -2911,7 +2921,7 @@ __global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
         }
         __syncthreads();  // prod / wt / vt are reused by the next tile
     }
-    if (VW == 0) return;
+    if (VW == 0 || dn) return;
     // this workgroup's partial sums: value i of [h_0..h_{nv-1}, q_0..q_{m-1}] comes from exactly one wave
     double *row = a.partials + (size_t)bid * kPartialLd;
 #pragma unroll
@@ -2967,7 +2977,7 @@ void iter_spmv_mdot(const IterA &a0, hipStream_t s, bool dots)
 template <int T, int G, int U, int MP>
 __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
 {
-    if (*b.done) return;
+    const int32_t dn = __builtin_nontemporal_load(b.done);  // looked at behind the first loads (see mdot_ws16_kernel)
     __shared__ double hs[kMaxNv], lam[kMaxNv * 8], ys[8], wraws[8], tus[8];
     __shared__ double red[T];
     const int nv = b.nv, m = b.m;
@@ -3029,13 +3039,22 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         wl = b.wl_in[threadIdx.x];
         sh = b.shat[threadIdx.x];
     }
+    double hi_pre = 0.0, qv_pre = 0.0, tbv_pre[8];
+    if (threadIdx.x < kWave) {
+        const int i = threadIdx.x;
+        hi_pre = i < nv ? b.dots[i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tbv_pre[r] = (r < m && i < nv) ? b.tb[i * 8 + r] : 0.0;
+        qv_pre = (i < m) ? b.dots[nv + i] : 0.0;
+    }
+    if (dn) return;
     if (threadIdx.x < kWave) {  // lane i owns basis vector i (nv <= 63)
         const int i = threadIdx.x;
-        const double hi = i < nv ? b.dots[i] : 0.0;
+        const double hi = hi_pre;
         double tbv[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) tbv[r] = (r < m && i < nv) ? b.tb[i * 8 + r] : 0.0;
-        const double qv = (i < m) ? b.dots[nv + i] : 0.0;
+        for (int r = 0; r < 8; ++r) tbv[r] = tbv_pre[r];
+        const double qv = qv_pre;
         if (i < nv) hs[i] = hi;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -3245,7 +3264,11 @@ void iter_maxpy_uhead(IterB b, hipStream_t s)
     const int64_t n2 = b.nl / 2;
     // thin workgroups below 0.5 M entries (as MAXPY), fat ones above
     const bool thin = n2 < (int64_t)kVecMaxBlocks * 2048;
-    const int T = thin ? 256 : 512, U = thin ? (n2 < (int64_t)kVecMaxBlocks * 1024 ? 1 : 2) : 4;
+    static const int t128 = [] { const char *e = getenv("SPK_B_T128"); return e ? atoi(e) : 0; }();
+    const int U = thin ? (n2 < (int64_t)kVecMaxBlocks * 1024 ? 1 : 2) : 4;
+    // the smallest vectors (<= 1024 tiles of 128 double2): two-wave workgroups, twice the waves in flight per CU
+    const bool tiny = thin && U == 1 && t128 && n2 <= (int64_t)1024 * 128;
+    const int T = tiny ? 128 : (thin ? 256 : 512);
     int64_t tiles = (n2 + (int64_t)T * U - 1) / ((int64_t)T * U);
     if (tiles < 1) tiles = 1;
     b.gmain = (int)std::min<int64_t>(tiles, thin ? 1024 : kVecMaxBlocks);
@@ -3260,6 +3283,7 @@ void iter_maxpy_uhead(IterB b, hipStream_t s)
 #define SPK_IB_MP(MPP)                                                           \
     do {                                                                         \
         if (!thin) SPK_IB(512, 4, 4, MPP);                                       \
+        else if (tiny) SPK_IB(128, 8, 1, MPP);                                   \
         else if (U == 2) { if (g2 == 16) SPK_IB(256, 16, 2, MPP); else SPK_IB(256, 8, 2, MPP); } \
         else if (g1 == 32) SPK_IB(256, 32, 1, MPP);                              \
         else if (g1 == 16) SPK_IB(256, 16, 1, MPP);                              \
@@ -3270,6 +3294,400 @@ void iter_maxpy_uhead(IterB b, hipStream_t s)
     else SPK_IB_MP(8);
 #undef SPK_IB_MP
 #undef SPK_IB
+}
+
+// ---------------------------------------------------------------------------
+// "BA": VecMAXPY (+ VecNorm, + the next PCApply) and the NEXT MatMult in ONE launch (opts.iteration_form = 4; single
+// rank, small vectors).  In the three-launch form kernel B ends, a boundary passes, and kernel A' starts streaming
+// the matrix: two ramps, two tails and a gap around a dependency that is LOCAL -- the SpMV of a row tile needs z~
+// only on the rows its columns touch (the adjacent grid lines).  Here a workgroup owns a fixed run of row tiles:
+//   phase B   w' = s_w w~ - sum_i (h_i sc_i) V~_i over its rows, ||w'||^2 partial, z~ = D w' - (B D)^T y~ stored
+//             write-through (sc1), c~ kept in LDS; then it raises ITS flag (sequence number, one line per workgroup)
+//   phase A   the matrix stream of its tiles is requested, then it waits for the flags of the workgroups that own the
+//             rows its columns touch (a handful), gathers z~ with sc1 loads and forms w~_next = A z~ + c~
+// while the last workgroup reduces the norm (beside phase A of the others) and runs the Givens step of THIS iteration.
+// No vector is normalised: the basis stays V~_i = w'_i with one scale factor sc_i = 1/||w'_i|| per vector, applied to the
+// reduced scalars (h_i = sc_i s_w (V~_i . w~), ...) -- mathematically the same Arnoldi relation, no VecScale pass at all.
+// Every wait is bounded; a flag that never rises raises the context's execution-error word.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void tile_col_range_kernel(const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
+                                                               const int32_t *__restrict__ tile_brow, int ntiles, int32_t *__restrict__ out)
+{
+    const int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int lo = INT32_MAX, hi = -1;
+    for (int q = browptr[tile_brow[t]] + (int)threadIdx.x; q < browptr[tile_brow[t + 1]]; q += kWave) {
+        const int c = bcol[q];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const int l2 = __shfl_down(lo, off, kWave), h2 = __shfl_down(hi, off, kWave);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (threadIdx.x == 0) {
+        out[2 * t] = lo;
+        out[2 * t + 1] = hi;
+    }
+}
+void tile_col_range(const int32_t *browptr, const int32_t *bcol, const int32_t *tile_brow, int ntiles, int32_t *out, hipStream_t s)
+{
+    if (ntiles == 0) return;
+    hipLaunchKernelGGL(tile_col_range_kernel, dim3(ntiles), dim3(kWave), 0, s, browptr, bcol, tile_brow, ntiles, out);
+}
+
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int G, int MP>
+__global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
+{
+    constexpr int T = kThreads;
+    constexpr int NP = MP > 0 ? MP : 1;
+    constexpr int kSteps = kBTile / T, kTB = 4;
+    // everything a workgroup needs to START is requested before anything is looked at (a launch of this size is a
+    // chain of a few memory round trips of ~1.3 us: measured 5.5 us from entry to the end of the scalar prologue when
+    // "done", the workgroup's tile list and its rows were read one after the other)
+    const int32_t dn = __builtin_nontemporal_load(p.done);
+    __shared__ double prod[kBTile * 4];
+    __shared__ double hs[kMaxNv], lam[kMaxNv * 8], ys[8], wraws[8], tus[8], red[T];
+    __shared__ int okw;
+    const int nv = p.nv, m = p.m;
+    const int nwg = 8 * p.slots;
+    const bool scalar_wg = (int)blockIdx.x == nwg;
+    // row-order index: phase B owns the double2 entries [rho chunk, (rho + 1) chunk) -- no table look-up in front
+    // of its loads; phase A owns the tiles wg[rho] = {t0, t1, first / last owner to wait for}
+    const int xcd = blockIdx.x & 7, kslot = blockIdx.x >> 3;
+    const int rho = scalar_wg ? 0 : xcd * p.slots + kslot;
+    const int64_t n2 = p.nl / 2;
+    const int64_t i2 = (int64_t)rho * p.chunk + threadIdx.x;
+    const bool active = !scalar_wg && (int)threadIdx.x < p.chunk && i2 < n2;
+    const bool dbg = p.dbg && (int)blockIdx.x == p.dbg_wg && threadIdx.x == 0;
+    if (dbg) p.dbg[0] = wall_clock64();
+
+    // ---- phase B loads first (they depend on nothing computed here)
+    double2 wv, dv, pe[NP], t0v[G];
+    wv.x = wv.y = dv.x = dv.y = 0.0;
+    if (active) {
+        wv = ld2(p.w, i2);
+        dv = ld2(p.dinv, i2);
+    }
+    if (MP > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const bool live = active && (p.packed ? 2 * q < m : q < m);
+            pe[q].x = pe[q].y = 0.0;
+            if (live) pe[q] = ld2s<true>(p.bd + (size_t)q * p.ldb, i2);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < G; ++v) {
+        const bool live = active && v < nv;
+        t0v[v].x = t0v[v].y = 0.0;
+        if (live) t0v[v] = ld2s<true>(p.V + (size_t)v * p.ldv, i2);
+    }
+    // phase A's descriptors ride along (uniform loads)
+    const int4 wgd = scalar_wg ? make_int4(0, 0, 0, -1) : reinterpret_cast<const int4 *>(p.wt)[rho];
+
+    // ---- scalars, by every workgroup: h_i = sc_i s_w (V~_i . w~), a_i = -h_i sc_i, B D w' by linearity
+    double lamv = 0.0;
+    const bool lam_mine = (int)threadIdx.x < nv * m;
+    if (lam_mine) lamv = p.V[(size_t)(threadIdx.x / m) * p.ldv + p.nl + (threadIdx.x % m)];
+    double wl = 0.0, sh = 1.0;
+    if ((int)threadIdx.x < m) {
+        wl = p.wl_in[threadIdx.x];
+        sh = p.shat[threadIdx.x];
+    }
+    const double s_w = p.sc[nv - 1];
+    double sci = 0.0, draw = 0.0, qraw = 0.0, tbv[8];
+    if (threadIdx.x < kWave) {  // lane i owns basis vector i (nv <= 63)
+        const int i = threadIdx.x;
+        sci = i < nv ? p.sc[i] : 0.0;
+        draw = i < nv ? p.dots[i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tbv[r] = (r < m && i < nv) ? p.tb_[i * 8 + r] : 0.0;
+        qraw = (i < m) ? p.dots[nv + i] : 0.0;
+    }
+    if (dn) return;  // (uniform over the launch: the gate word cannot change while its workgroups start)
+    if (threadIdx.x < kWave) {
+        const int i = threadIdx.x;
+        const double hi = sci * s_w * draw;
+        const double qv = s_w * qraw;
+        if (i < nv) hs[i] = hi * sci;  // MAXPY coefficient of V~_i (sign applied at use)
+        if (scalar_wg && i < nv) p.hbuf[i] = hi;  // the Hessenberg column of this iteration
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < m) {  // uniform
+                const double tsum = wave_sum(hi * sci * tbv[r]);
+                const double qr = __shfl(qv, r, kWave);
+                if (i == 0) tus[r] = qr - tsum;  // B D w' = B D w - sum h_i (B D v_i)
+            }
+        }
+    }
+    if (lam_mine) lam[threadIdx.x] = lamv;
+    for (int t = threadIdx.x + T; t < nv * m; t += T) lam[t] = p.V[(size_t)(t / m) * p.ldv + p.nl + (t % m)];
+    __syncthreads();
+    if ((int)threadIdx.x < NP && MP > 0) {
+        const int r = threadIdx.x;
+        double y = 0.0, wraw = 0.0;
+        if (r < m) {
+            wraw = s_w * wl;
+            for (int i = 0; i < nv; ++i) wraw += -hs[i] * lam[i * m + r];  // the MAXPY of the multiplier entries
+            y = -(wraw - tus[r]) / sh;
+        }
+        wraws[r] = wraw;
+        ys[r] = y;
+    }
+    __syncthreads();
+    double yv[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) yv[r] = MP > 0 ? ys[r] : 0.0;
+    if (dbg) p.dbg[1] = wall_clock64();  // prologue done
+
+    if (scalar_wg) {
+        // ---- the scalar / reducing workgroup
+        if ((int)threadIdx.x < m) {
+            const int r = threadIdx.x;
+            double w1 = tus[r];
+            if (p.fact == SPK_SCHUR_FULL)
+                for (int q = 0; q < m; ++q) w1 -= p.gram[r * m + q] * ys[q];
+            p.w[p.nl + r] = wraws[r];
+            p.tb_[(size_t)nv * 8 + r] = tus[r];
+            if (!p.last) {
+                p.zout[p.nl + r] = ys[r];
+                p.wnext[p.nl + r] = w1;
+                p.wl_out[r] = w1;
+            }
+        }
+        __syncthreads();
+        final_reduce(p.partials, nwg, kPartialLd, 1, red, FinErr{p.err, p.fin_ticks});
+        if (threadIdx.x == 0) {
+            double tot = red[0];
+            for (int r = 0; r < m; ++r) tot += p.lam_in_dot ? wraws[r] * wraws[r] : 0.0;
+            red[0] = tot;
+        }
+        __syncthreads();
+        if (p.ar.P) peer_allreduce_block(p.ar, red, 1, p.nrm_out);
+        else if (threadIdx.x == 0) p.nrm_out[0] = red[0];
+        __syncthreads();
+        if (threadIdx.x == 0) p.sc[nv] = inv_norm(p.ar.P ? p.nrm_out[0] : red[0]);
+        __syncthreads();
+        // Givens step of THIS iteration: every workgroup of the launch passed its look at `done` long ago, and
+        // none of them feeds another reduction of this launch
+        givens_block(p.ka, p.loc, p.hbuf, p.nrm_out);
+        return;
+    }
+
+    // phase A's matrix descriptors: requested now, consumed after the flag
+    int4 td[kTB];
+#pragma unroll
+    for (int j = 0; j < kTB; ++j)
+        td[j] = (wgd.x + j < wgd.y) ? reinterpret_cast<const int4 *>(p.tdesc)[wgd.x + j] : make_int4(0, 0, 0, 0);
+
+    // ---- phase B arithmetic
+    double2 sv;
+    sv.x = sv.y = 0.0;
+    if (MP > 0) {
+        if (p.packed) {
+#pragma unroll
+            for (int q = 0; q < NP / 2; ++q) {
+                sv.x += pe[q].x * yv[2 * q];
+                sv.y += pe[q].y * yv[2 * q + 1];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                sv.x += pe[r].x * yv[r];
+                sv.y += pe[r].y * yv[r];
+            }
+        }
+    }
+    wv.x *= s_w;
+    wv.y *= s_w;
+#pragma unroll
+    for (int v = 0; v < G; ++v) {
+        const double ai = v < nv ? -hs[v] : 0.0;
+        wv.x += ai * t0v[v].x;
+        wv.y += ai * t0v[v].y;
+    }
+    for (int g0 = G; g0 < nv; g0 += G) {
+        double2 tt[G];
+        double ai[G];
+#pragma unroll
+        for (int v = 0; v < G; ++v) {
+            const bool live = active && g0 + v < nv;
+            ai[v] = g0 + v < nv ? -hs[g0 + v] : 0.0;
+            tt[v].x = tt[v].y = 0.0;
+            if (live) tt[v] = ld2s<true>(p.V + (size_t)(g0 + v) * p.ldv, i2);
+        }
+#pragma unroll
+        for (int v = 0; v < G; ++v) {
+            wv.x += ai[v] * tt[v].x;
+            wv.y += ai[v] * tt[v].y;
+        }
+    }
+    if (dbg) p.dbg[2] = wall_clock64() + (unsigned long long)(wv.x == 1.2345e300);  // MAXPY arithmetic done (loads arrived)
+    double nrm = 0.0;
+    if (active) {
+        double2 zz;
+        nrm = wv.x * wv.x + wv.y * wv.y;
+        zz.x = wv.x * dv.x;
+        zz.y = wv.y * dv.y;
+        if (MP > 0 && p.fact == SPK_SCHUR_FULL) {
+            zz.x -= sv.x;
+            zz.y -= sv.y;
+        }
+        reinterpret_cast<double2 *>(p.w)[i2] = wv;
+        if (!p.last) {
+            // write-through: read by OTHER workgroups of this launch (z~ gathered, c~ by the owner of the row's tile)
+            st_agent(p.zout + 2 * i2, zz.x);
+            st_agent(p.zout + 2 * i2 + 1, zz.y);
+            if (MP > 0) {
+                st_agent(p.wnext + 2 * i2, sv.x / dv.x);
+                st_agent(p.wnext + 2 * i2 + 1, sv.y / dv.y);
+            }
+        }
+    }
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const double sw = wave_sum(nrm);
+        if (lane == 0) red[wave] = sw;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left before the flag may rise
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int j = 0; j < T / kWave; ++j) tsum += red[j];
+        publish(p.partials + (size_t)blockIdx.x * kPartialLd, tsum);
+        if (!p.last) __hip_atomic_store(p.flags + (size_t)rho * 32, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (dbg) p.dbg[3] = wall_clock64();  // flag raised
+    const int t0 = wgd.x, t1 = wgd.y;
+    if (p.last || t0 >= t1) return;
+
+    // ---- phase A: the next product of this workgroup's tiles.  The matrix stream of ALL its tiles is requested at
+    // once (descriptors are here already), then the wait, then ONE agent-scope acquire per workgroup (this CU's L1
+    // forgets what it may hold; the producers stored write-through, and no line of z~ can sit in this XCD's L2 yet: it
+    // was never read in this launch), then ONE gather round trip for all tiles on plain cached loads (every z~ entry is
+    // used 18 times; sc1 gathers, tried first, sent each use over the fabric as an 8-byte request).
+    int c[kTB][kSteps];
+    double2 tp[kTB][kSteps], bo[kTB][kSteps], xv[kTB][kSteps];
+#pragma unroll
+    for (int j = 0; j < kTB; ++j) {
+        if (t0 + j < t1) {  // uniform
+            const int b0 = td[j].z, cntb = td[j].w - td[j].z;
+#pragma unroll
+            for (int i = 0; i < kSteps; ++i) {
+                const int q = i * T + threadIdx.x;
+                c[j][i] = 0;
+                if (q < cntb) {
+                    c[j][i] = __builtin_nontemporal_load(p.bcol + b0 + q);
+                    tp[j][i] = ld2s<true>(p.vtop, b0 + q);
+                    bo[j][i] = ld2s<true>(p.vbot, b0 + q);
+                }
+            }
+        }
+    }
+    {   // wait for the owners of the rows my columns (and my own rows' c~) live in (bounded)
+        const int wlo = wgd.z, whi = wgd.w;
+        if (threadIdx.x == 0) okw = 1;
+        __syncthreads();
+        for (int w = wlo + (int)threadIdx.x; w <= whi; w += T) {
+            const uint32_t *f = p.flags + (size_t)w * 32;
+            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq) {
+                const unsigned long long tw0 = wall_clock64();
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.seq) break;
+                    if (wall_clock64() - tw0 > (unsigned long long)p.fin_ticks) {
+                        okw = 0;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!okw) {  // an owner never finished its phase B: execution failure (reported by the host), no product
+            if (threadIdx.x == 0 && p.err) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (dbg) p.dbg[4] = wall_clock64();  // neighbours' flags seen
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (dbg) p.dbg[5] = wall_clock64();  // acquire done
+    }
+#pragma unroll
+    for (int j = 0; j < kTB; ++j) {
+        if (t0 + j < t1) {
+            const int cntb = td[j].w - td[j].z;
+#pragma unroll
+            for (int i = 0; i < kSteps; ++i) {
+                const int q = i * T + threadIdx.x;
+                if (q < cntb) xv[j][i] = reinterpret_cast<const double2 *>(p.zout)[c[j][i]];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kTB; ++j) {
+        if (t0 + j < t1) {  // uniform
+            const int tb0 = td[j].x, tb1 = td[j].y;
+            const int b0 = td[j].z, cntb = td[j].w - td[j].z;
+            const int nr = 2 * (tb1 - tb0), r0 = 2 * tb0;
+            const int lr = threadIdx.x;
+            // row thread's own operands (row extent, c~) requested before the products
+            int k0 = 0, k1 = 0;
+            double cpre = 0.0;
+            if (lr < nr) {
+                const int br = tb0 + (lr >> 1);
+                k0 = p.browptr[br] - b0;
+                k1 = p.browptr[br + 1] - b0;
+                if (MP > 0) cpre = p.wnext[r0 + lr];
+            }
+#pragma unroll
+            for (int i = 0; i < kSteps; ++i) {
+                const int q = i * T + threadIdx.x;
+                if (q < cntb) {
+                    double2 p0, p1;
+                    p0.x = tp[j][i].x * xv[j][i].x;
+                    p0.y = tp[j][i].y * xv[j][i].y;
+                    p1.x = bo[j][i].x * xv[j][i].x;
+                    p1.y = bo[j][i].y * xv[j][i].y;
+                    *reinterpret_cast<double2 *>(prod + 4 * q) = p0;
+                    *reinterpret_cast<double2 *>(prod + 4 * q + 2) = p1;
+                }
+            }
+            __syncthreads();
+            if (lr < nr) {
+                const int half = lr & 1;
+                double sr = 0.0;
+                for (int k = k0; k < k1; ++k) {
+                    const double2 pp = *reinterpret_cast<const double2 *>(prod + 4 * k + 2 * half);
+                    sr += pp.x;
+                    sr += pp.y;
+                }
+                sr += cpre;
+                p.wnext[r0 + lr] = sr;
+            }
+            __syncthreads();  // prod is rewritten by the next tile
+            if (dbg) p.dbg[6 + j] = wall_clock64();  // tile done
+        }
+    }
+}
+
+void iter_ba(const IterBA &p, hipStream_t s)
+{
+    const dim3 grid(8 * p.slots + 1), block(kThreads);
+    if (p.nv + p.m > kMaxNv - 1) fail(SPK_ERR_ARG, "iter_ba: %d values exceed one reduction", p.nv + p.m);
+    if (8 * p.slots > kMaxBlocks) fail(SPK_ERR_ARG, "iter_ba: %d workgroups exceed the partials buffer", 8 * p.slots);
+    if (p.m == 0) hipLaunchKernelGGL((iter_ba_kernel<8, 0>), grid, block, 0, s, p);
+    else if (p.m <= 4) hipLaunchKernelGGL((iter_ba_kernel<8, 4>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((iter_ba_kernel<8, 8>), grid, block, 0, s, p);
 }
 
 // -ksp_gmres_cgs_refinement_type: mode 2 (always) refines unless done; mode 1 (ifneeded)
@@ -3309,7 +3727,7 @@ void krylov_refine_merge(const KrylovArrays &ka, int loc, double *dots, const do
 
 // back substitution for the loc_done columns built in this cycle; the triangle is staged
 // in LDS by the whole workgroup first (450 dependent global loads took 47 us)
-__global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka)
+__global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka, const double *sc)
 {
     __shared__ double Hs[(kMaxNv) * (kMaxNv + 1)];
     __shared__ double rss[kMaxNv + 2], ys[kMaxNv + 2];
@@ -3334,11 +3752,12 @@ __global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka)
         }
         ys[k] = t / piv;
     }
-    for (int k = 0; k < n; ++k) ka.nrs[k] = ys[k];
+    // (un-normalised Z~_k of the BA iteration: x += sum y_k sc_k Z~_k)
+    for (int k = 0; k < n; ++k) ka.nrs[k] = sc ? ys[k] * sc[k] : ys[k];
 }
-void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s)
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc)
 {
-    hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka);
+    hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka, sc);
 }
 
 }  // namespace k

@@ -301,7 +301,83 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
                 for (int32_t br = 0; br < Ab.nbrows && !Ab.long_rows; ++br) Ab.long_rows = brp[(size_t)br + 1] - brp[(size_t)br] > k::kBTile;
                 Ab.ntiles = (int32_t)tb.size() - 1;
                 Ab.tile_brow.upload(tb.data(), tb.size(), 8);
+                {
+                    std::vector<int32_t> td((size_t)4 * Ab.ntiles);
+                    for (int32_t t = 0; t < Ab.ntiles; ++t) {
+                        td[(size_t)4 * t] = tb[(size_t)t];
+                        td[(size_t)4 * t + 1] = tb[(size_t)t + 1];
+                        td[(size_t)4 * t + 2] = brp[(size_t)tb[(size_t)t]];
+                        td[(size_t)4 * t + 3] = brp[(size_t)tb[(size_t)t + 1]];
+                    }
+                    Ab.tile_desc.upload(td.data(), td.size(), 8);
+                }
                 Ab.ok = true;
+                // BA iteration kernel: workgroup rho (row order) owns ba_tb consecutive tiles of its XCD's range; it
+                // may start its SpMV phase once the owners of the rows its block columns touch have stored their z~
+                Ab.ba_ok = false;
+                if (!Ab.long_rows && Ab.ntiles > 0) {
+                    const int TB = 4, tpx = (Ab.ntiles + 7) / 8;
+                    DevBuf<int32_t> rng;
+                    rng.alloc_raw((size_t)2 * Ab.ntiles, 8);
+                    k::tile_col_range(Ab.browptr.p, Ab.bcol.p, Ab.tile_brow.p, Ab.ntiles, rng.p, s);
+                    std::vector<int32_t> rh((size_t)2 * Ab.ntiles);
+                    SPK_HIP(hipMemcpyAsync(rh.data(), rng.p, rh.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                    SPK_HIP(hipStreamSynchronize(s));
+                    // groups of <= TB consecutive tiles with <= 256 block rows (one double2 per thread in phase B),
+                    // XCD by XCD (each XCD keeps its contiguous run of tiles, as in the SpMV kernels)
+                    std::vector<std::vector<std::pair<int32_t, int32_t>>> groups(8);
+                    bool fits = true;
+                    int S = 1;
+                    for (int x = 0; x < 8; ++x) {
+                        const int tbeg = std::min(x * tpx, (int)Ab.ntiles), tend = std::min((x + 1) * tpx, (int)Ab.ntiles);
+                        int t = tbeg;
+                        while (t < tend) {
+                            int t1 = t;
+                            while (t1 < tend && t1 - t < TB && tb[(size_t)t1 + 1] - tb[(size_t)t] <= 256) ++t1;
+                            if (t1 == t) { fits = false; break; }   // one tile beyond 256 block rows
+                            groups[(size_t)x].push_back({t, t1});
+                            t = t1;
+                        }
+                        S = std::max(S, (int)groups[(size_t)x].size());
+                    }
+                    const int nwg = 8 * S;
+                    if (nwg > 1024) fits = false;
+                    // phase B deals the double2 entries (= block rows) out evenly, in the same row order: workgroup rho owns
+                    // [rho chunk, (rho + 1) chunk) -- no table in front of its loads; one entry per thread
+                    const int chunk = (Ab.nbrows + nwg - 1) / nwg;
+                    if (chunk > 256 || chunk < 1) fits = false;
+                    // per workgroup rho = x S + k: {t0, t1, first owner, last owner it waits for}: the owners (phase B) of the
+                    // block rows its columns touch and of its own rows (their c~)
+                    std::vector<int32_t> wt((size_t)4 * nwg, 0);
+                    for (int rho = 0; rho < nwg && fits; ++rho) {
+                        const int x = rho / S, kk = rho % S;
+                        const auto &gx = groups[(size_t)x];
+                        int32_t *w4 = wt.data() + (size_t)4 * rho;
+                        if (kk < (int)gx.size()) {
+                            const int t0 = gx[(size_t)kk].first, t1 = gx[(size_t)kk].second;
+                            int32_t lo = tb[(size_t)t0], hi = tb[(size_t)t1] - 1;
+                            for (int t = t0; t < t1; ++t) {
+                                lo = std::min(lo, rh[(size_t)2 * t]);
+                                hi = std::max(hi, rh[(size_t)2 * t + 1]);
+                            }
+                            w4[0] = t0;
+                            w4[1] = t1;
+                            w4[2] = std::max(0, lo / chunk);
+                            w4[3] = std::min(nwg - 1, hi / chunk);
+                        } else {  // no tiles: waits for nobody
+                            w4[0] = w4[1] = 0;
+                            w4[2] = 0;
+                            w4[3] = -1;
+                        }
+                    }
+                    if (fits) {
+                        Ab.ba_slots = S;
+                        Ab.ba_tb = TB;
+                        Ab.ba_chunk = chunk;
+                        Ab.ba_wt.upload(wt.data(), wt.size(), 8);
+                        Ab.ba_ok = true;
+                    }
+                }
             } else {
                 Ab.browptr.release(); Ab.bcol.release(); Ab.vtop.release(); Ab.vbot.release();
             }
@@ -918,6 +994,18 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // 56.4 us (two: the fused SpMV + MDot kernel is a chain of latencies at <= 4 workgroups per CU);
     // 256^2 36.2 / 30.0 / 40.1, 512^2 71.8 / 68.1 / 81.0; the full 1024^2 grid 215 / 218 / 236 (four stays)
     const bool three = two && form != SPK_ITER_TWO_LAUNCH;
+    // BA: MAXPY + the next SpMV in one launch behind neighbour flags, un-normalised basis (two launches per
+    // iteration: MDot, BA).  Single rank; opt-in (opts.iteration_form = 4 / SPK_ITER_FORM=4)
+    const bool ba = two_ok && form == SPK_ITER_BA && c->Ab.ba_ok && c->peers.empty() && c->comm->size() == 1 &&
+                    (c->m <= 4 || 8 * c->Ab.ba_slots + 1 <= 512);   // every workgroup resident at once (registers: 3 / 2 per CU)
+    if (ba) {
+        const size_t nfl = (size_t)(8 * c->Ab.ba_slots + 1) * 32;
+        if (c->ba_flags.n < nfl) {
+            c->ba_flags.alloc(nfl);
+            c->ba_seq = 0;
+        }
+        if (c->ba_sc.n < (size_t)mk + 2) c->ba_sc.alloc((size_t)mk + 2);
+    }
     if (two && c->zun.n < (size_t)ld) c->zun.alloc((size_t)ld);
     const int lam_in_dot = c->comm->rank() == 0 ? 1 : 0;
 
@@ -930,7 +1018,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
         else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
-        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two) ? c->ka.tb : nullptr, m);
+        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two || ba) ? c->ka.tb : nullptr, m, ba ? c->ba_sc.p : nullptr);
         if (!head) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
@@ -943,7 +1031,63 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             const int32_t *done = &c->kst.p->skip_iter;  // the gate of everything inside an iteration
             double *w = Vj(loc + 1);
             double *db = dotsbuf(loc), *nb = nrmbuf(loc);
-            if (two) {
+            if (ba) {
+                if (loc == 0) {
+                    // first iteration of a cycle: the classic head on the normalised r, then the plain product
+                    if (fused)
+                        k::fused_head(Vj(0), nrmbuf(1), w1side, c->dinv.p, bdp, ld, c->shat.p, c->gram.p, c->schur_fact, nl, m,
+                                      Zj(0), w, c->ka, -1, dotsbuf(1), done, s, nullptr, bpk);
+                    else
+                        k::fused_head(Vj(0), nrmbuf(1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER, nl, 0,
+                                      Zj(0), nullptr, c->ka, -1, dotsbuf(1), done, s, nullptr);
+                    k::spmv_bcsr(c->Ab, Zj(0), w, nullptr, nullptr, done, s, fused, nullptr);
+                    if (fused) k::copy_small(w + nl, wl(0), m, done, s);
+                }
+                // raw inner products of the un-normalised basis with w~ (and B D w~); scaled where they are consumed
+                {
+                    const bool one = loc + 1 + m <= 40;
+                    const bool spl = bpk && one;
+                    k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s, fused ? (spl ? c->bdpk.p : c->bd.p) : nullptr,
+                            fused ? m : 0, spl ? 1 : 0);
+                }
+                k::IterBA p{};
+                p.browptr = c->Ab.browptr.p; p.bcol = c->Ab.bcol.p; p.vtop = c->Ab.vtop.p; p.vbot = c->Ab.vbot.p;
+                p.tile_brow = c->Ab.tile_brow.p; p.ntiles = c->Ab.ntiles; p.tiles_per_xcd = (c->Ab.ntiles + 7) / 8;
+                p.slots = c->Ab.ba_slots; p.tb = c->Ab.ba_tb; p.chunk = c->Ab.ba_chunk; p.nbr = nullptr; p.wt = c->Ab.ba_wt.p;
+                p.tdesc = c->Ab.tile_desc.p;
+                p.flags = c->ba_flags.p; p.seq = ++c->ba_seq;
+                p.V = V; p.ldv = ld; p.nv = loc + 1; p.dots = db; p.sc = c->ba_sc.p; p.tb_ = c->ka.tb;
+                p.w = w; p.dinv = c->dinv.p; p.bd = bdp; p.ldb = ld; p.shat = c->shat.p; p.gram = c->gram.p;
+                p.fact = fused ? c->schur_fact : SPK_SCHUR_LOWER;
+                p.nl = nl; p.m = m; p.packed = bpk;
+                p.last = loc + 1 >= mk ? 1 : 0;
+                p.zout = p.last ? nullptr : Zj(loc + 1);
+                p.wnext = p.last ? nullptr : Vj(loc + 2);
+                p.wl_in = wl(loc); p.wl_out = wl(loc + 1);
+                p.hbuf = sm2;
+                p.lam_in_dot = lam_in_dot;
+                p.partials = c->partials.p; p.nrm_out = nb;
+                p.err = c->errw.p; p.fin_ticks = c->fin_ticks;
+                p.ka = c->ka; p.loc = loc; p.done = done;
+                static const char *dbgenv = getenv("SPK_BA_DEBUG");
+                static DevBuf<unsigned long long> dbgbuf;
+                const bool dbgnow = dbgenv && loc == 20 && cycles == 1;
+                if (dbgnow) {
+                    if (!dbgbuf.p) dbgbuf.alloc(16);
+                    p.dbg = dbgbuf.p;
+                    p.dbg_wg = atoi(dbgenv);
+                }
+                k::iter_ba(p, s);
+                if (dbgnow) {
+                    unsigned long long h[16];
+                    SPK_HIP(hipStreamSynchronize(s));
+                    SPK_HIP(hipMemcpy(h, dbgbuf.p, sizeof h, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[BA wg %d, loc %d] prologue %.2f  maxpy %.2f  flag %.2f  waited %.2f  acquire %.2f  tiles %.2f %.2f %.2f %.2f us (from entry)\n",
+                            p.dbg_wg, loc, (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0, (h[4] - h[0]) / 100.0,
+                            (h[5] - h[0]) / 100.0, (h[6] - h[0]) / 100.0, (h[7] - h[0]) / 100.0, (h[8] - h[0]) / 100.0, (h[9] - h[0]) / 100.0);
+                }
+                last = -1;  // the Givens step of this iteration ran inside the launch
+            } else if (two) {
                 k::SendRanges sr0 = c->send_ranges;
                 const bool packed = sr0.n > 0;
                 if (loc == 0) {
@@ -967,6 +1111,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 k::IterA a{};
                 a.browptr = c->Ab.browptr.p; a.bcol = c->Ab.bcol.p; a.vtop = c->Ab.vtop.p; a.vbot = c->Ab.vbot.p;
                 a.tile_brow = c->Ab.tile_brow.p; a.ntiles = c->Ab.ntiles; a.tiles_per_xcd = (c->Ab.ntiles + 7) / 8;
+                a.tdesc = reinterpret_cast<const int4 *>(c->Ab.tile_desc.p);
                 a.slots = 0;  // set by the launcher
                 a.od = c->n_ghost > 0 ? c->offdiag() : k::OffDiag{nullptr, nullptr, nullptr, nullptr};
                 a.zsrc = zsrc;
@@ -1050,8 +1195,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
             }
-            if (two) {
-                // (orthogonalisation done above, inside the two launches)
+            if (two || ba) {
+                // (orthogonalisation done above, inside the launches)
             } else if (o.orthog == SPK_ORTHOG_MGS) {
                 // KSPGMRESModifiedGramSchmidtOrthogonalization: one dot + one axpy per basis vector
                 for (int j = 0; j <= loc; ++j) {
@@ -1121,7 +1266,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
         if (head && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
-        k::krylov_cycle_end(c->ka, s);
+        k::krylov_cycle_end(c->ka, s, ba ? c->ba_sc.p : nullptr);
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);
