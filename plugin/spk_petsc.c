@@ -390,6 +390,11 @@ static PetscErrorCode KSPSolve_SPK(KSP ksp)
         ierr = PetscOptionsGetInt(((PetscObject)ksp)->options, ((PetscObject)ksp)->prefix, "-spk_single_reduce", &sr, NULL); CHKERRQ(ierr);
         o.single_reduce = (int32_t)sr;
     }
+    {   /* private option: how an iteration is launched (spk_opts.iteration_form; 0 = automatic) */
+        PetscInt form = 0;
+        ierr = PetscOptionsGetInt(((PetscObject)ksp)->options, ((PetscObject)ksp)->prefix, "-spk_iteration_form", &form, NULL); CHKERRQ(ierr);
+        o.iteration_form = (int32_t)form;
+    }
     ierr = SpkGather(d->glue, ksp->vec_rhs, d->glue->xbuf); CHKERRQ(ierr);
     if (o.guess_nonzero) { ierr = SpkGather(d->glue, ksp->vec_sol, d->glue->ybuf); CHKERRQ(ierr); }
     SPK_CHK(d->glue->ctx, spk_fgmres(d->glue->ctx, d->glue->xbuf, d->glue->ybuf, SPK_MEM_HOST, &o, &res, NULL, 0));

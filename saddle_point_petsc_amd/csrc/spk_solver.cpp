@@ -1070,7 +1070,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 p.err = c->errw.p; p.fin_ticks = c->fin_ticks;
                 p.ka = c->ka; p.loc = loc; p.done = done;
                 static const char *dbgenv = getenv("SPK_BA_DEBUG");
-                static DevBuf<unsigned long long> dbgbuf;
+                static DevBuf<unsigned long long> &dbgbuf = *new DevBuf<unsigned long long>();  // (never freed: no hipFree at exit)
                 const bool dbgnow = dbgenv && loc == 20 && cycles == 1;
                 if (dbgnow) {
                     if (!dbgbuf.p) dbgbuf.alloc(16);
