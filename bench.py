@@ -64,7 +64,7 @@ def spmv_bytes(nrows, nnz):
     return 12 * nnz + 4 * (nrows + 1) + 16 * nrows
 
 
-def solve_bytes(n, nnz, nnzB, restart, steps, planes, m, spmv_matrix_bytes=None):
+def solve_bytes(n, nnz, nnzB, restart, steps, planes, m, spmv_matrix_bytes=None, unnormalised=True):
     """Algorithmic bytes of ONE spk_fgmres call that executes exactly `steps` iterations of the
     head-kernel paths, summed over the iterations and restart cycles ACTUALLY
     executed -- iteration i of the solve has j = i mod restart basis vectors behind it, and a cycle end
@@ -75,6 +75,11 @@ def solve_bytes(n, nnz, nnzB, restart, steps, planes, m, spmv_matrix_bytes=None)
       SpMV  y (+)= A z                   : matrix + 4 n (row pointers) + x + y out [+ y in]
       MDot                               : V_0..V_j and w                        (j + 2) vec
       MAXPY + norm [+ B D w']            : V_0..V_j, w in/out, planes            (j + 3 + planes) vec
+    unnormalised (the default form, opts.iteration_form 0/5: no head launch after the first iteration of a cycle --
+    the MAXPY pass also applies the preconditioner to the w' it holds, and nothing is normalised in memory):
+      MDot [+ B D w~]                    : V_0..V_j, w, planes                   (j + 2 + planes) vec
+      MAXPY + norm + next PCApply        : V_0..V_j, w, dinv, planes in; w', z [, c] out   (j + 5 + [1] + planes) vec
+      (iteration 0 of a cycle still pays the head: (4 + [1] + planes) vec, and its MAXPY the same as above)
     Per started cycle with L iterations: ||r|| [+ B D r] (1 + m) vec, x += Z y (L + 2) vec, true residual
     (plain K x: matrix + B and B^T entries, b - K x: 5 vec).  Once per solve: ||b|| (1 vec).
     The matrix term is 12 B per stored non-zero (CSR) unless spmv_matrix_bytes gives the
@@ -88,9 +93,14 @@ def solve_bytes(n, nnz, nnzB, restart, steps, planes, m, spmv_matrix_bytes=None)
         L = min(restart, steps - done)
         total += (1 + (m if saddle else 0)) * vec            # cycle start
         for j in range(L):
-            total += (4 + (1 if saddle else 0) + planes) * vec
             total += mat + 4 * (n + 1) + 2 * vec + (vec if saddle else 0)
-            total += (j + 2) * vec + (j + 3 + planes) * vec
+            if unnormalised:
+                if j == 0:
+                    total += (4 + (1 if saddle else 0) + planes) * vec
+                total += (j + 2 + planes) * vec + (j + 5 + (1 if saddle else 0) + planes) * vec
+            else:
+                total += (4 + (1 if saddle else 0) + planes) * vec
+                total += (j + 2) * vec + (j + 3 + planes) * vec
         total += (L + 2) * vec                               # x += Z y
         total += mat + 4 * (n + 1) + 2 * vec + 2 * 12 * nnzB + 4 * n + 5 * vec   # true residual of the restart
         done += L
@@ -118,7 +128,7 @@ def main():
     ap.add_argument("--inner-sweeps", type=int, default=0, help="FP32 damped-Jacobi Richardson sweeps standing for "
                                                                 "diag(A)^-1 in the PC (BASELINE config 5's mixed FP32 inner solve)")
     ap.add_argument("--inner-omega", type=float, default=0.8)
-    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="opts.iteration_form: 0 auto, 1 four launches per iteration, 2 two launches, 3 three launches")
     ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
     args = ap.parse_args()
@@ -293,6 +303,7 @@ def main():
     achieved_layout = spi["layout_bytes"] / (spmv_ms * 1e-3) / 1e9
     # the variant the fused Schur iteration launches: y += A x (y pre-loaded with B^T lambda): 8n more bytes
     acc_ms = ctx.time_kernel("spmv_acc", 0, 20, args.spmv_reps)
+    ride_ms = ctx.time_kernel("spmv_ride", 0, 20, args.spmv_reps)   # y = A x with the rider: the Jacobi iteration's launch
     # per-rank diagnostics of the communicator, gathered to rank 0: an N-GPU line explains itself
     rank_info = [ctx.comm_info()]
     if dist is not None and world > 1:
@@ -320,7 +331,7 @@ def main():
     head_path = args.inner_sweeps == 0 and ((saddle and planes > 0) or (not saddle and sz["n_local"] % 2 == 0))
     mrows = B.nrows if saddle else 0
     in_solver_acc = saddle and planes > 0            # the loop launches y += A x (else the plain product)
-    loop_ms = acc_ms if in_solver_acc else spmv_ms
+    loop_ms = acc_ms if in_solver_acc else ride_ms
     loop_alg = alg_bytes + (8 * sz["n_local"] if in_solver_acc else 0)
     loop_layout = spi["layout_bytes"] + (8 * sz["n_local"] if in_solver_acc else 0)
     loop_gbps, loop_layout_gbps = loop_alg / (loop_ms * 1e-3) / 1e9, loop_layout / (loop_ms * 1e-3) / 1e9
@@ -366,8 +377,9 @@ def main():
         # Schur path (y pre-loaded with B^T lambda: one more vector read), the plain product otherwise.
         "roofline": {"bound": "hbm",
                      "kernel": ("spmv_bcsr_kernel" if spi["format"] != "csr" else "spmv_stream_kernel")
-                               + ("<.., ACC=true>: y += A x, as launched by the fused Schur iteration" if in_solver_acc
-                                  else ": y = A x, as launched by the iteration"),
+                               + ("<.., ACC=true, RIDE=true>: y += A x, as launched by the fused Schur iteration "
+                                  "(Givens rider in workgroup 0)" if in_solver_acc
+                                  else "<.., ACC=false, RIDE=true>: y = A x, as launched by the iteration"),
                      "format": spi["format"], "ms": loop_ms,
                      "achieved": loop_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": min(loop_gbps, loop_layout_gbps) / HBM_PEAK_GBS,
@@ -386,12 +398,14 @@ def main():
         mat_layout = spi["layout_bytes"] - 4 * (sz["n_local"] + 1) - 16 * sz["n_local"]
         models = {}
         for name, steps_, secs in (("timed_steps", args.steps, elapsed), ("full_cycles", full_steps, elapsed_full)):
-            b_csr = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows)
-            b_lay = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows, mat_layout)
+            un = args.iter_form in (0, 5)       # the form the solver takes for these options (spk_solver.cpp: un3)
+            b_csr = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows, None, un)
+            b_lay = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows, mat_layout, un)
             models[name] = {"steps": steps_, "bytes_per_iteration_csr_model": b_csr / steps_,
                             "bytes_per_iteration_layout": b_lay / steps_,
                             "achieved_gbps_csr_model": b_csr / secs / 1e9, "achieved_gbps_layout": b_lay / secs / 1e9,
-                            "frac_of_peak": min(b_csr, b_lay) / secs / 1e9 / HBM_PEAK_GBS}
+                            "frac_of_peak": min(b_csr, b_lay) / secs / 1e9 / HBM_PEAK_GBS,
+                            "form": "unnormalised three-launch" if un else "head + SpMV + MDot + MAXPY"}
         out["iteration_model"] = models
     if not residual_ok:
         # a wrong halo or all-reduce shows here: the number would describe a broken solver

@@ -106,19 +106,28 @@ typedef struct spk_opts {
                                reductions otherwise). */
     int32_t iteration_form; /* how the head-kernel paths launch one classical Gram-Schmidt iteration (same
                                algorithm, two reductions, norms taken from w' itself):
-                               SPK_ITER_AUTO (0): three launches below ~1 M local rows, four above;
-                               SPK_ITER_FOUR_LAUNCH (1): head, SpMV, MDot, MAXPY;
+                               SPK_ITER_AUTO (0): SPK_ITER_UNNORM wherever it applies (classical Gram-Schmidt
+                               without refinement, two reductions), else four launches;
+                               SPK_ITER_UNNORM (5): three launches on an UN-NORMALISED basis -- VecMDot (raw inner
+                               products and B D w~), VecMAXPY + norm + the next PCApply (+ B^T part), plain MatMult
+                               carrying the Givens step in one extra workgroup.  V~_j = h_{j,j-1} v_j is stored with
+                               a scale factor beside it and every consumer scales the scalars, never the vectors:
+                               no VecScale traffic, either matrix format, any number of ranks;
+                               SPK_ITER_FOUR_LAUNCH (1): head (VecScale + PCApply), SpMV, MDot, MAXPY;
                                SPK_ITER_TWO_LAUNCH (2): SpMV with MDot in its tile epilogues (VecScale of v and z
                                folded in), MAXPY with the norm and the next iteration's preconditioner + B^T
                                product on the un-normalised vector (B D w' by linearity from B D w).  Needs
                                the 2x2-blocked matrix layout and restart + m <= 62; otherwise four launches;
                                SPK_ITER_THREE_LAUNCH (3): as 2 with VecMDot (h and B D w) as a launch of its own;
                                SPK_ITER_BA (4, single rank, small systems): VecMAXPY + norm + next PCApply AND the next
-                               MatMult in one launch behind neighbour flags, un-normalised basis with one scale factor
-                               per vector (two launches per iteration; measured no faster than 3: bandwidth-bound). */
+                               MatMult in one launch behind neighbour flags, un-normalised basis (two launches per
+                               iteration; measured no faster than 5: bandwidth-bound).
+                               Measured us per iteration, forms 1 / 3 / 5: 1/8 slab of 1024^2 47.9 / 44.7 / 43.3,
+                               512^2 71.8 / 67.6 / 66.0, 1024^2 219.7 / 218 / 209.2 (profiles/r02*). */
     int32_t reserved;
 } spk_opts;
-enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3, SPK_ITER_BA = 4 };
+enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3, SPK_ITER_BA = 4,
+       SPK_ITER_UNNORM = 5 };
 
 typedef struct spk_result {
     int32_t its;            /* KSPGetIterationNumber   */

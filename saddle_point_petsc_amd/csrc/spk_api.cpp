@@ -532,9 +532,14 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
     auto run = [&]() {
         if (w == "spmv") spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s);
         else if (w == "spmv_bcsr") { if (!c->Ab.ok) spk::fail(SPK_ERR_STATE, "no 2x2-blocked copy"); spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s); }
-        else if (w == "spmv_acc") {  // y += A x in the active format: the variant the fused Schur path launches
-            if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s, true);
-            else spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s, true);
+        else if (w == "spmv_acc" || w == "spmv_ride") {
+            // y += A x (spmv_ride: y = A x) in the active format, as the default iteration launches it: with the Givens
+            // rider in workgroup 0 once a solve has left its state behind (the rider finds `done` set and leaves)
+            spk::k::GivensRider gr{c->ka, 0, c->small.p, c->small.p + 64, nullptr};
+            const spk::k::GivensRider *rp = c->kst.p ? &gr : nullptr;
+            const bool acc = w == "spmv_acc";
+            if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
+            else spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
         }
         else if (w == "mult") spk::op_mult(c, x, y, nullptr);
         else if (w == "pc") { if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "pc not set up"); spk::op_pc_apply(c, x, y, nullptr); }
@@ -546,6 +551,10 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
         else if (w == "bt_update") { if (!c->have_B || !c->pc_ready) spk::fail(SPK_ERR_STATE, "no B / pc"); spk::k::bt_update(1, c->Bt, c->dinv.p, x, c->small.p + 200, y, nullptr, s); }
         else spk::fail(SPK_ERR_ARG, "spk_time_kernel: unknown kernel '%s'", which);
     };
+    if ((w == "spmv_acc" || w == "spmv_ride") && c->kst.p) {
+        const int32_t one = 1;   // (krylov_init of the next solve resets it)
+        SPK_HIP(hipMemcpyAsync(&c->kst.p->done, &one, sizeof one, hipMemcpyHostToDevice, s));
+    }
     hipEvent_t e0, e1;
     SPK_HIP(hipEventCreate(&e0));
     SPK_HIP(hipEventCreate(&e1));

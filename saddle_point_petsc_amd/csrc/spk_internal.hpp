@@ -204,6 +204,8 @@ public:
     // throws SPK_ERR_COMM when a device-side wait of this backend has timed out (call after a sync)
     virtual void check(hipStream_t s) { (void)s; }
     virtual const char *name() const { return "self"; }
+    // true when the Krylov all-reduces ride in the finish of the reducing kernels (fused_allreduce returns windows)
+    virtual bool fuses() const { return false; }
     // in-place sum over ranks of `count` doubles in device memory, stream-ordered
     virtual void allreduce_sum(double *dev, int count, hipStream_t s) { (void)dev; (void)count; (void)s; }
     // exchange of packed halo segments: sendbuf[send_off[p]..] -> peer p,
@@ -328,12 +330,16 @@ struct SendRanges {
     unsigned long long *stats;
 };
 
-// y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel
+// y = A x  (+ Bt-rows * lam when bt != nullptr; y += when accumulate); CSR stream kernel.
+// rider: one extra workgroup of the launch runs a pending Givens step beside the row tiles (GivensRider below)
+struct GivensRider;
 void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-          const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
+          const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr,
+          const GivensRider *rider = nullptr);
 // same product from the 2x2-blocked copy (bitwise the same sums: CSR order is kept)
 void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-               const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr);
+               const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr,
+               const GivensRider *rider = nullptr);
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
 // KSPSetOperators on the device: count off-rank entries per row, exclusive scan, split, 2x2 blocking
 void csr_count_off(const int32_t *rowptr, const int32_t *colidx, int nrows, int64_t lo, int64_t hi, int64_t ncols, int32_t *cnt,
@@ -424,6 +430,16 @@ struct KrylovArrays {
     int32_t hist_cap, ldh;
     int32_t tentative;  // 1: the recurrence may end a cycle, only a true residual may end the solve
 };
+// The Givens step of iteration `loc` (Hessenberg column h[0..loc], ||w'||^2 in *nrm2), carried by workgroup 0 of a
+// product launch: the serial chain runs beside the row tiles instead of at the tail of the MAXPY launch's reducer.
+// The tiles of that launch read the gate words BEFORE the step may set them (they compute a product nobody uses when
+// the step converges: no reduction in the launch depends on them).
+struct GivensRider {
+    KrylovArrays ka;
+    int32_t loc;     // < 0: no rider
+    const double *h, *nrm2;
+    double *sc;      // un-normalised basis: sc[loc + 1] = 1 / sqrt(*nrm2) is set first (nullptr: not)
+};
 // ---- two-launch iteration (spk_kernels.hip, "Two-launch iteration") ----
 // kernel A: w = s (A z~ + c~), v and z normalised on the way, h = V^T w and q = B D w from the tile epilogues
 struct IterA {
@@ -487,6 +503,13 @@ struct IterB {
     SendRanges sr;
     int gmain;           // set by the launcher
     const int32_t *done;
+    // un-normalised basis (opts.iteration_form = 5): sc != nullptr -- dots are RAW inner products of V~_i with w~, the
+    // scale factors sc[i] = 1 / ||w'_i|| are applied to the scalars here (h_i = sc_i s_w dots_i, MAXPY coefficient
+    // h_i sc_i, w = s_w w~); zun is Z_{loc+1} itself; the reducer stores sc[nv], the scaled Hessenberg column (hbuf)
+    // and runs the Givens step of THIS iteration.  No vector is ever normalised, no pass exists for it.
+    double *sc, *hbuf, *wl_out;
+    KrylovArrays ka;
+    int loc;
 };
 // dots = false: the SpMV / normalisation part alone (three-launch form; one tile per workgroup: slots = tiles_per_xcd)
 void iter_spmv_mdot(const IterA &a, hipStream_t s, bool dots = true);

@@ -307,6 +307,20 @@ __device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const doub
 // non-temporal loads on the matrix stream: 102 us (slower; not used for CSR).
 constexpr int kCsrTile = 2048;
 
+__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate = nullptr);  // below
+__device__ __forceinline__ double inv_norm(double nrm2)  // the VecScale guard of the head kernels
+{
+    const double tt = sqrt(nrm2);
+    return tt > 1e-300 ? 1.0 / tt : 1.0;
+}
+__device__ __forceinline__ void givens_rider(const GivensRider &gr)
+{
+    // un-normalised basis: the scale factor of the vector the MAXPY launch just wrote (its norm is all-reduced by now)
+    // (nothing compounds: V~_j = w' of the product of the NORMALISED v_{j-1}, so ||V~_j|| = h_{j,j-1} <= ||K M^-1||)
+    if (gr.sc && threadIdx.x == 0) gr.sc[gr.loc + 1] = inv_norm(*gr.nrm2);
+    givens_block(gr.ka, gr.loc, gr.h, gr.nrm2);
+}
+
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row)
 {
     const int kTileNnz = kCsrTile, kTileRows = kThreads;
@@ -322,20 +336,25 @@ void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &til
     }
 }
 
-template <bool NT, int TILE, int T>
+template <bool NT, int TILE, int T, bool RIDE>
 __global__ __launch_bounds__(T) void spmv_stream_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
     const double *__restrict__ val, const int32_t *__restrict__ tile_row, int ntiles,
     int tiles_per_xcd, const double *__restrict__ x, double *__restrict__ y,
     const int32_t *__restrict__ bt_rowptr, const int32_t *__restrict__ bt_colidx,
     const double *__restrict__ bt_val, const double *__restrict__ lam, int accumulate, OffDiag od,
-    const int32_t *__restrict__ done)
+    const int32_t *__restrict__ done, GivensRider gr)
 {
     if (done && *done) return;
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles
+        givens_rider(gr);
+        return;
+    }
     // workgroups b, b+8, ... share an XCD (round-robin dispatch): give each XCD
     // a contiguous run of row tiles so the x window stays in ITS L2.
-    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || t >= ntiles) return;
+    const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
+    const int t = (bx & 7) * tiles_per_xcd + (bx >> 3);
+    if ((bx >> 3) >= tiles_per_xcd || t >= ntiles) return;
 
     __shared__ double prod[TILE + 8];
     const int r0 = tile_row[t], r1 = tile_row[t + 1];
@@ -408,15 +427,31 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
     }
 }
 
-void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-          const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *od)
+static GivensRider no_rider()
 {
-    if (A.nrows == 0) return;
+    GivensRider g{};
+    g.loc = -1;
+    return g;
+}
+
+void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+          const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *od, const GivensRider *rider)
+{
+    if (A.nrows == 0) {
+        if (rider) krylov_givens(rider->ka, rider->loc, rider->h, rider->nrm2, s);
+        return;
+    }
     const int tpx = (A.ntiles + 7) / 8;
     const OffDiag o = od ? *od : OffDiag{nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads>), dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p,
-                       A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, o, done);
+    const GivensRider gr = rider ? *rider : no_rider();
+    if (rider)
+        hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads, true>), dim3(tpx * 8 + 1), dim3(kThreads), 0, s,
+                           A.rowptr.p, A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, o, done, gr);
+    else
+        hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads, false>), dim3(tpx * 8), dim3(kThreads), 0, s,
+                           A.rowptr.p, A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
+                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, o, done, gr);
 }
 
 // ---------------------------------------------------------------------------
@@ -442,17 +477,22 @@ void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &
 
 // ACC: y += A x (the fused Schur path pre-loads y with B^T lambda); a separate instantiation so
 // that profiles list the plain product (the one bench.py times for the roofline) on its own line
-template <bool NT, bool ACC>
+template <bool NT, bool ACC, bool RIDE>
 __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
     const double *__restrict__ vtop, const double *__restrict__ vbot,
     const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd,
     const double *__restrict__ x, double *__restrict__ y, const int32_t *__restrict__ bt_rowptr,
     const int32_t *__restrict__ bt_colidx, const double *__restrict__ bt_val,
-    const double *__restrict__ lam, OffDiag od, const int32_t *__restrict__ done)
+    const double *__restrict__ lam, OffDiag od, const int32_t *__restrict__ done, GivensRider gr)
 {
     if (done && *done) return;
-    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles
+        givens_rider(gr);
+        return;
+    }
+    const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
+    const int t = (bx & 7) * tiles_per_xcd + (bx >> 3);
     if (t >= ntiles) return;
     __shared__ double prod[kBTile * 4];
     const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
@@ -537,20 +577,30 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
 }
 
 void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
-               const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *odp)
+               const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *odp, const GivensRider *rider)
 {
-    if (A.nbrows == 0) return;
+    if (A.nbrows == 0) {
+        if (rider) krylov_givens(rider->ka, rider->loc, rider->h, rider->nrm2, s);
+        return;
+    }
     const int tpx = (A.ntiles + 7) / 8;
     const OffDiag od = odp ? *odp : OffDiag{nullptr, nullptr, nullptr, nullptr};
+    const GivensRider gr = rider ? *rider : no_rider();
+    const int nride = rider ? 1 : 0;
     // non-temporal loads on the matrix planes (read once per SpMV): 70.7 -> 61.3 us in the same run
-    if (accumulate)
-        hipLaunchKernelGGL((spmv_bcsr_kernel<true, true>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p,
-                           A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done);
-    else
-        hipLaunchKernelGGL((spmv_bcsr_kernel<true, false>), dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p,
-                           A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
-                           bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done);
+    // (the rider is a template flag: the plain product keeps its registers and its 16 KB of LDS)
+#define SPK_LAUNCH_BCSR(ACC, RIDE)                                                                                         \
+    hipLaunchKernelGGL((spmv_bcsr_kernel<true, ACC, RIDE>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
+                       A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,                \
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
+    if (accumulate) {
+        if (rider) SPK_LAUNCH_BCSR(true, true);
+        else SPK_LAUNCH_BCSR(true, false);
+    } else {
+        if (rider) SPK_LAUNCH_BCSR(false, true);
+        else SPK_LAUNCH_BCSR(false, false);
+    }
+#undef SPK_LAUNCH_BCSR
 }
 
 // ---------------------------------------------------------------------------
@@ -2186,7 +2236,7 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t 
 // iteration (done, skip_iter) are not stored here but handed back as gate[0], gate[1]; the caller
 // stores them once no workgroup of ITS launch can still be about to read them (kernel A of the
 // two-launch iteration: its workgroups must all take the same branch, they feed one reduction).
-__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate = nullptr)
+__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
 {
     __shared__ double Hc[kMaxNv + 2], Hr[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
     KrylovState *st = ka.st;
@@ -2715,12 +2765,6 @@ void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double
 // and is the reducer (and the all-reducer across ranks) of the launch.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double ld1nt(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ double inv_norm(double nrm2)
-{
-    const double tt = sqrt(nrm2);
-    return tt > 1e-300 ? 1.0 / tt : 1.0;
-}
-
 template <int VW, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void iter_spmv_mdot_kernel(IterA a)
 {
@@ -3039,10 +3083,12 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         wl = b.wl_in[threadIdx.x];
         sh = b.shat[threadIdx.x];
     }
-    double hi_pre = 0.0, qv_pre = 0.0, tbv_pre[8];
+    double hi_pre = 0.0, qv_pre = 0.0, tbv_pre[8], sci = 1.0;
+    const double s_w = b.sc ? b.sc[nv - 1] : 1.0;   // w = s_w w~ (un-normalised basis); 1 otherwise
     if (threadIdx.x < kWave) {
         const int i = threadIdx.x;
         hi_pre = i < nv ? b.dots[i] : 0.0;
+        if (b.sc) sci = i < nv ? b.sc[i] : 0.0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) tbv_pre[r] = (r < m && i < nv) ? b.tb[i * 8 + r] : 0.0;
         qv_pre = (i < m) ? b.dots[nv + i] : 0.0;
@@ -3050,12 +3096,15 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
     if (dn) return;
     if (threadIdx.x < kWave) {  // lane i owns basis vector i (nv <= 63)
         const int i = threadIdx.x;
-        const double hi = hi_pre;
+        // un-normalised basis: h_i = sc_i s_w (V~_i . w~); the MAXPY coefficient of V~_i and the weight of B D V~_i is h_i sc_i
+        const double hi = b.sc ? sci * s_w * hi_pre : hi_pre;
+        const double ci = b.sc ? hi * sci : hi;
         double tbv[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) tbv[r] = tbv_pre[r];
-        const double qv = qv_pre;
-        if (i < nv) hs[i] = hi;
+        for (int r = 0; r < 8; ++r) tbv[r] = tbv_pre[r] * (b.sc ? sci : 1.0);
+        const double qv = qv_pre * s_w;
+        if (i < nv) hs[i] = ci;
+        if (b.sc && (int)blockIdx.x == gmain + nhalo && i < nv) b.hbuf[i] = hi;  // the Hessenberg column (reducer only)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (r < m) {  // uniform
@@ -3072,7 +3121,7 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         const int r = threadIdx.x;
         double y = 0.0, wraw = 0.0;
         if (r < m) {
-            wraw = wl;
+            wraw = s_w * wl;
             for (int i = 0; i < nv; ++i) wraw += -hs[i] * lam[i * m + r];  // the MAXPY of the multiplier entries
             y = -(wraw - tus[r]) / sh;
         }
@@ -3083,6 +3132,13 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
     double yv[NP];
 #pragma unroll
     for (int r = 0; r < NP; ++r) yv[r] = MP > 0 ? ys[r] : 0.0;
+    if (b.sc && have) {  // w = s_w w~
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wv[u].x *= s_w;
+            wv[u].y *= s_w;
+        }
+    }
 
     if ((int)blockIdx.x == gmain + nhalo) {
         // ---- the scalar / reducing workgroup: multiplier entries of w', z~, c~; B D w' for the recurrence
@@ -3094,7 +3150,8 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
             b.w[b.nl + r] = wraws[r];
             b.zun[b.nl + r] = ys[r];
             b.c[b.nl + r] = w1;
-            b.tb[(size_t)nv * 8 + r] = tus[r];  // un-normalised; kernel A of the next iteration scales it
+            b.tb[(size_t)nv * 8 + r] = tus[r];  // un-normalised; kernel A of the next iteration scales it (or nobody: b.sc)
+            if (b.sc) b.wl_out[r] = w1;
         }
         __syncthreads();
         final_reduce(b.partials, gmain, kPartialLd, 1, red, FinErr{b.err, b.fin_ticks});
@@ -3106,6 +3163,11 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         __syncthreads();
         if (b.ar.P) peer_allreduce_block(b.ar, red, 1, b.out);
         else if (threadIdx.x == 0) b.out[0] = red[0];
+        if (b.sc) {
+            // un-normalised basis: the new vector's scale factor and the Givens step of this iteration ride in the
+            // product launch that follows (GivensRider) -- here they would be a serial tail of the whole launch, and
+            // would see the local norm when the all-reduce is a launch of its own
+        }
         return;
     }
     if (!is_main) {  // peer-store halo: unpack this rank's ghost rows (see fused_head_kernel)
@@ -3242,7 +3304,16 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
         }
         tile += gmain;
         have = tile * (T * U) < n2;
-        if (have) load_tile(tile);
+        if (have) {
+            load_tile(tile);
+            if (b.sc) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wv[u].x *= s_w;
+                    wv[u].y *= s_w;
+                }
+            }
+        }
     }
     // ||w'||^2 of this workgroup's entries.  The partial goes to slot bx -- the FIRST TILE this workgroup
     // streamed -- so that the reducer adds the partials in tile order whichever way the grid was walked

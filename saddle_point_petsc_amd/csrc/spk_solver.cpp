@@ -892,8 +892,10 @@ static void ensure_krylov(spk_ctx *c, const spk_opts &o)
     if (mk < 1 || mk > k::kMaxNv - 2) fail(SPK_ERR_ARG, "fgmres: restart %d outside [1,%d]", mk, k::kMaxNv - 2);
     const int32_t hist_cap = (int32_t)std::min<int64_t>((int64_t)std::max(o.max_it, 0) + 2, 1 << 22);
     if (c->ws_restart != mk) {
-        c->V.alloc((size_t)c->ld * (mk + 1));
-        c->Z.alloc((size_t)c->ld * mk);
+        // one more of each than the cycle uses: the un-normalised three-launch form lets the last iteration of a cycle
+        // write its (unused) next vectors too
+        c->V.alloc((size_t)c->ld * (mk + 2));
+        c->Z.alloc((size_t)c->ld * (mk + 1));
         c->ws_restart = mk;
     }
     const int ldh = mk + 2;
@@ -980,19 +982,19 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const bool single = head && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                         o.single_reduce == 1 && mk + c->m <= k::kMaxNv - 1;
 
-    // two-launch iteration (spk_kernels.hip): same classical Gram-Schmidt with two reductions, MDot inside the
-    // SpMV launch, the next PC / B^T product inside the MAXPY launch.  Default below ~1 M rows, where launch
-    // boundaries and reduction tails outweigh the bytes; opts.iteration_form / SPK_ITER_FORM force either.
+    // How one classical Gram-Schmidt iteration (two reductions) is launched on the head-kernel paths
+    // (opts.iteration_form / SPK_ITER_FORM; include/spk.h lists the forms and their measured times).
     int form = o.iteration_form;
     if (const char *e = getenv("SPK_ITER_FORM")) form = atoi(e);
+    // AUTO: three launches on an UN-normalised basis -- MDot (raw inner products), MAXPY + norm + next PCApply, plain SpMV
+    // with the Givens step and the new scale factor in one extra workgroup (GivensRider).  V~_j = h_{j,j-1} v_j: nothing
+    // compounds, no vector is ever scaled in memory.  Either matrix format, any number of ranks, any transport.
+    const bool un3 = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
+                     mk + c->m <= k::kMaxNv - 2 && (form == SPK_ITER_UNNORM || form == SPK_ITER_AUTO);
     const bool two_ok = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                         c->spmv_format == 1 && !c->Ab.long_rows && mk + c->m <= k::kMaxNv - 2;
-    const bool two = two_ok && (form == SPK_ITER_TWO_LAUNCH || form == SPK_ITER_THREE_LAUNCH ||
-                                (form == SPK_ITER_AUTO && nl < (1 << 20)));
-    // three launches: VecMDot (h and B D w) stays a launch of its own behind the SpMV.  What AUTO takes for
-    // small vectors: measured on the 1/8 slab of the 1024^2 grid 47.9 (four launches) / 44.8 (three) /
-    // 56.4 us (two: the fused SpMV + MDot kernel is a chain of latencies at <= 4 workgroups per CU);
-    // 256^2 36.2 / 30.0 / 40.1, 512^2 71.8 / 68.1 / 81.0; the full 1024^2 grid 215 / 218 / 236 (four stays)
+    const bool two = two_ok && !un3 && (form == SPK_ITER_TWO_LAUNCH || form == SPK_ITER_THREE_LAUNCH);
+    // forms 2 / 3 (normalised basis, MDot inside / behind the SpMV launch): opt-in, kept for comparison
     const bool three = two && form != SPK_ITER_TWO_LAUNCH;
     // BA: MAXPY + the next SpMV in one launch behind neighbour flags, un-normalised basis (two launches per
     // iteration: MDot, BA).  Single rank; opt-in (opts.iteration_form = 4 / SPK_ITER_FORM=4)
@@ -1004,6 +1006,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             c->ba_flags.alloc(nfl);
             c->ba_seq = 0;
         }
+    }
+    if (ba || un3) {
         if (c->ba_sc.n < (size_t)mk + 2) c->ba_sc.alloc((size_t)mk + 2);
     }
     if (two && c->zun.n < (size_t)ld) c->zun.alloc((size_t)ld);
@@ -1018,7 +1022,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
         else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
-        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two || ba) ? c->ka.tb : nullptr, m, ba ? c->ba_sc.p : nullptr);
+        k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two || ba || un3) ? c->ka.tb : nullptr, m,
+                              (ba || un3) ? c->ba_sc.p : nullptr);
         if (!head) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
@@ -1031,25 +1036,66 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             const int32_t *done = &c->kst.p->skip_iter;  // the gate of everything inside an iteration
             double *w = Vj(loc + 1);
             double *db = dotsbuf(loc), *nb = nrmbuf(loc);
-            if (ba) {
+            if (ba || un3) {
+                // the product K z~ of a vector (halo, then diagonal and off-rank columns in one kernel), either format
+                auto product = [&](const double *zvec, double *wvec, bool halo_done, const k::GivensRider *rider = nullptr) {
+                    k::SendRanges srp = c->send_ranges;
+                    if (!c->peers.empty() && !halo_done) {
+                        if (srp.n == 0) k::gather(zvec, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
+                        c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
+                    }
+                    const k::OffDiag od = c->offdiag();
+                    const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;
+                    if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
+                    else k::spmv(c->Ad, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
+                };
                 if (loc == 0) {
                     // first iteration of a cycle: the classic head on the normalised r, then the plain product
+                    k::SendRanges sr0 = c->send_ranges;
+                    const bool packed = sr0.n > 0;
+                    const bool inhead = packed && c->comm->fused_halo(sr0, c->xghost.p);
                     if (fused)
                         k::fused_head(Vj(0), nrmbuf(1), w1side, c->dinv.p, bdp, ld, c->shat.p, c->gram.p, c->schur_fact, nl, m,
-                                      Zj(0), w, c->ka, -1, dotsbuf(1), done, s, nullptr, bpk);
+                                      Zj(0), w, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr, bpk);
                     else
                         k::fused_head(Vj(0), nrmbuf(1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER, nl, 0,
-                                      Zj(0), nullptr, c->ka, -1, dotsbuf(1), done, s, nullptr);
-                    k::spmv_bcsr(c->Ab, Zj(0), w, nullptr, nullptr, done, s, fused, nullptr);
+                                      Zj(0), nullptr, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr);
+                    product(Zj(0), w, inhead);
                     if (fused) k::copy_small(w + nl, wl(0), m, done, s);
                 }
                 // raw inner products of the un-normalised basis with w~ (and B D w~); scaled where they are consumed
                 {
                     const bool one = loc + 1 + m <= 40;
                     const bool spl = bpk && one;
-                    k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db), done, s, fused ? (spl ? c->bdpk.p : c->bd.p) : nullptr,
+                    const k::PeerAR ar = one ? c->comm->fused_allreduce(loc + 2 + (fused ? m : 0), k::kStatArDots) : k::PeerAR{};
+                    k::mdot(V, ld, loc + 1, w, N, n_dot, c->fin(db, ar), done, s, fused ? (spl ? c->bdpk.p : c->bd.p) : nullptr,
                             fused ? m : 0, spl ? 1 : 0);
+                    if (!ar.P) c->comm->allreduce_sum(db, loc + 2 + (fused ? m : 0), s);
                 }
+                if (un3) {
+                    const k::PeerAR ar2 = c->comm->fused_allreduce(1, k::kStatArNorm);
+                    k::IterB b{};
+                    b.V = V; b.ldv = ld; b.nv = loc + 1; b.dots = db; b.tb = c->ka.tb;
+                    b.w = w; b.dinv = c->dinv.p; b.bd = bdp; b.ldb = ld; b.shat = c->shat.p; b.gram = c->gram.p;
+                    b.fact = fused ? c->schur_fact : SPK_SCHUR_LOWER;
+                    b.nl = nl; b.m = m; b.packed = bpk;
+                    b.zun = Zj(loc + 1); b.c = fused ? Vj(loc + 2) : nullptr; b.wl_in = wl(loc); b.wl_out = wl(loc + 1);
+                    b.lam_in_dot = lam_in_dot;
+                    b.partials = c->partials.p; b.out = nb; b.ar = ar2; b.err = c->errw.p; b.fin_ticks = c->fin_ticks;
+                    b.sc = c->ba_sc.p; b.hbuf = sm2; b.ka = c->ka; b.loc = loc;
+                    k::SendRanges sr = c->send_ranges;
+                    const bool inb = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
+                    if (sr.n > 0) b.sr = sr;
+                    b.done = done;
+                    k::iter_maxpy_uhead(b, s);
+                    if (!ar2.P) c->comm->allreduce_sum(nb, 1, s);
+                    // the Givens step of this iteration (and the new vector's scale factor) ride in the next product launch
+                    k::GivensRider gr{c->ka, loc, sm2, nb, c->ba_sc.p};
+                    if (loc + 1 < mk) product(Zj(loc + 1), Vj(loc + 2), inb, &gr);
+                    else k::krylov_givens(c->ka, loc, sm2, nb, s);
+                    last = -1;
+                }
+                if (ba) {
                 k::IterBA p{};
                 p.browptr = c->Ab.browptr.p; p.bcol = c->Ab.bcol.p; p.vtop = c->Ab.vtop.p; p.vbot = c->Ab.vbot.p;
                 p.tile_brow = c->Ab.tile_brow.p; p.ntiles = c->Ab.ntiles; p.tiles_per_xcd = (c->Ab.ntiles + 7) / 8;
@@ -1078,6 +1124,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     p.dbg_wg = atoi(dbgenv);
                 }
                 k::iter_ba(p, s);
+                last = -1;  // the Givens step of this iteration ran inside the launch
                 if (dbgnow) {
                     unsigned long long h[16];
                     SPK_HIP(hipStreamSynchronize(s));
@@ -1086,7 +1133,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                             p.dbg_wg, loc, (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0, (h[4] - h[0]) / 100.0,
                             (h[5] - h[0]) / 100.0, (h[6] - h[0]) / 100.0, (h[7] - h[0]) / 100.0, (h[8] - h[0]) / 100.0, (h[9] - h[0]) / 100.0);
                 }
-                last = -1;  // the Givens step of this iteration ran inside the launch
+                }
             } else if (two) {
                 k::SendRanges sr0 = c->send_ranges;
                 const bool packed = sr0.n > 0;
@@ -1195,7 +1242,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 op_pc_apply(c, Vj(loc), Zj(loc), done);  // z_j = M^-1 v_j
                 op_mult(c, Zj(loc), w, done);            // w = K z_j
             }
-            if (two || ba) {
+            if (two || ba || un3) {
                 // (orthogonalisation done above, inside the launches)
             } else if (o.orthog == SPK_ORTHOG_MGS) {
                 // KSPGMRESModifiedGramSchmidtOrthogonalization: one dot + one axpy per basis vector
@@ -1266,7 +1313,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
         if (head && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
-        k::krylov_cycle_end(c->ka, s, ba ? c->ba_sc.p : nullptr);
+        k::krylov_cycle_end(c->ka, s, (ba || un3) ? c->ba_sc.p : nullptr);
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);

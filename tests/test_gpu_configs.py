@@ -279,3 +279,32 @@ def test_converged_default_reference_norm_on_device(spk, oracle):
             assert info["reason"] == io["reason"] and abs(info["its"] - io["its"]) <= 1, (kw, info, io)
             if info["reason"] > 0:
                 assert relerr(x, xo) < 1e-6 or np.linalg.norm(x - xo) < 1e-6 * np.linalg.norm(xs)
+
+
+# --------------------------------------------------------------------------- iteration forms
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("pc", ["jacobi", "schur"])
+def test_every_iteration_form_against_the_oracle(spk, oracle, form, pc):
+    """opts.iteration_form 1..5 (include/spk.h) are re-schedulings of the same classical Gram-Schmidt FGMRES:
+    every one of them must reproduce the oracle's residual history and solution (AUTO picks form 5 where it
+    applies, so the rest of the suite covers that one; a form that does not apply to a set-up falls back)."""
+    M = 48
+    A, f = spk.AssembleOperator_Laplace(M)
+    if pc == "schur":
+        B, g = spk.AssembleOperator_Constraints(M)
+        rhs = np.concatenate([f, g])
+        xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=oracle.SCHUR_FULL, rtol=1e-9)
+    else:
+        B, rhs = None, f
+        xo, io = oracle.fgmres(A, rhs, pc_type=oracle.PC_JACOBI, rtol=1e-9)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        if B is not None:
+            c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR if B is not None else spk.PC_JACOBI, 3)
+        x, info = c.fgmres(rhs, rtol=1e-9, iteration_form=form)
+    assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 1
+    k = min(len(info["history"]), len(io["history"])) - 1
+    assert np.allclose(info["history"][:k], io["history"][:k], rtol=1e-6)
+    assert relerr(x, xo) < 1e-7
+
