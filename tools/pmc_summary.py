@@ -8,7 +8,8 @@ request of a wide (16 B/lane) coalesced read, i.e. exactly half the bytes ->
 doubled here; WRITE_SIZE is exact.  The correction is calibrated in the same
 pass on scale_dev_kernel, a pure 16 B/lane stream of known size.
 
-usage: tools/pmc_summary.py gpurun_out/pmc_r01_FETCH_SIZE gpurun_out/pmc_r01_WRITE_SIZE r01
+usage: tools/pmc_summary.py gpurun_out/pmc_r01_FETCH_SIZE gpurun_out/pmc_r01_WRITE_SIZE r01 [notraffic]
+(notraffic: a pass on another workload than the 1024 x 1024 grid -- profiles/spmv_traffic.json is left alone)
 """
 import collections, csv, glob, json, os, statistics, sys
 
@@ -35,10 +36,21 @@ for k in sorted(set(fe) | set(wr)):
     f, w = fe.get(k, 0.0), wr.get(k, 0.0)
     out["kernels"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
-tr = {"source": f"profiles/{tag}_pmc_summary.json", "workload": "1024x1024 grid A-block SpMV"}
+# the variant bench.py's roofline names first: y += A x with the Givens rider (<NT, ACC=true, RIDE=true>), then any other;
+# a format this pass did not run keeps the figure (and source) already in the file
+if len(sys.argv) > 4 and sys.argv[4] == "notraffic":
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
+tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+try:
+    tr = json.load(open(tpath))
+except Exception:  # noqa: BLE001
+    tr = {}
+tr["workload"] = "1024x1024 grid A-block SpMV"
 for key, pat in (("csr", "spmv_stream"), ("bcsr2x2", "spmv_bcsr")):
-    sp = [v for k, v in out["kernels"].items() if pat in k]
+    sp = sorted((k for k in out["kernels"] if pat in k), key=lambda k: (0 if "true, true, true>" in k else 1, k))
     if sp:
-        tr["hbm_bytes_per_launch_" + key] = sp[0]["hbm_bytes_corrected"]
-json.dump(tr, open(os.path.join(ROOT, "profiles", "spmv_traffic.json"), "w"), indent=1)
+        tr["hbm_bytes_per_launch_" + key] = out["kernels"][sp[0]]["hbm_bytes_corrected"]
+        tr["source" if key == "bcsr2x2" else "source_csr"] = f"profiles/{tag}_pmc_summary.json ({sp[0]})"
+json.dump(tr, open(tpath, "w"), indent=1)
 print(json.dumps(out, indent=1))
