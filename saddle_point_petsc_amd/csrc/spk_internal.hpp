@@ -437,8 +437,10 @@ struct KrylovArrays {
 struct GivensRider {
     KrylovArrays ka;
     int32_t loc;     // < 0: no rider
-    const double *h, *nrm2;
+    const double *h;
+    double *nrm2;
     double *sc;      // un-normalised basis: sc[loc + 1] = 1 / sqrt(*nrm2) is set first (nullptr: not)
+    PeerAR ar;       // P != 0: *nrm2 is first collected from the peers (the MAXPY launch posted its contribution)
 };
 // ---- two-launch iteration (spk_kernels.hip, "Two-launch iteration") ----
 // kernel A: w = s (A z~ + c~), v and z normalised on the way, h = V^T w and q = B D w from the tile epilogues
@@ -505,11 +507,13 @@ struct IterB {
     const int32_t *done;
     // un-normalised basis (opts.iteration_form = 5): sc != nullptr -- dots are RAW inner products of V~_i with w~, the
     // scale factors sc[i] = 1 / ||w'_i|| are applied to the scalars here (h_i = sc_i s_w dots_i, MAXPY coefficient
-    // h_i sc_i, w = s_w w~); zun is Z_{loc+1} itself; the reducer stores sc[nv], the scaled Hessenberg column (hbuf)
-    // and runs the Givens step of THIS iteration.  No vector is ever normalised, no pass exists for it.
+    // h_i sc_i, w = s_w w~); zun is Z_{loc+1} itself; the reducer stores the scaled Hessenberg column (hbuf).  sc[nv] and
+    // the Givens step of THIS iteration follow in the rider of the next product launch (GivensRider).  No vector is ever
+    // normalised, no pass exists for it.
     double *sc, *hbuf, *wl_out;
     KrylovArrays ka;
     int loc;
+    int ar_post_only;    // peer-store: only POST ||w'||^2 (that rider collects the sum: peer_allreduce_post / _wait)
 };
 // dots = false: the SpMV / normalisation part alone (three-launch form; one tile per workgroup: slots = tiles_per_xcd)
 void iter_spmv_mdot(const IterA &a, hipStream_t s, bool dots = true);

@@ -268,6 +268,41 @@ __device__ __forceinline__ double join_halves(uint32_t lo, uint32_t hi)
 // adjacent lanes) sum vals[0..count) over the ranks into out[0..count): every rank adds the
 // P contributions in rank order, its own included, so all ranks hold the same bits.
 // No barrier inside; vals may be LDS or global, out may alias vals.
+// The two halves of peer_allreduce_block, for a sum whose consumer sits in a LATER launch: `post` (threads
+// 0 .. 2*count-1) stores this rank's contribution into every rank's window and returns; `wait` (same threads, any
+// later launch of the stream) collects the P contributions.  What runs between the two overlaps the link latency.
+__device__ __forceinline__ void peer_allreduce_post(const PeerAR &a, const double *vals, int count)
+{
+    const int t = threadIdx.x;
+    if (t >= 2 * count) return;
+    const int slot = (int)(a.seq & (kArSlots - 1));
+    const uint32_t half = reinterpret_cast<const uint32_t *>(vals)[t];
+    const unsigned long long g = ((unsigned long long)a.seq << 32) | half;
+    const size_t mine = ((size_t)slot * a.P + a.me) * kArGranules + t;
+    for (int p = 0; p < a.P; ++p) st_sys(a.win[p] + mine, g);
+}
+__device__ __forceinline__ void peer_allreduce_wait(const PeerAR &a, int count, double *out)
+{
+    const int t = threadIdx.x;
+    if (t >= 2 * count) return;
+    const int slot = (int)(a.seq & (kArSlots - 1));
+    const unsigned long long *own = a.win[a.me] + (size_t)slot * a.P * kArGranules + t;
+    const unsigned long long tw0 = (a.stats && t == 0) ? wall_clock64() : 0ull;
+    double sum = 0.0;
+    bool ok = true;
+    for (int p = 0; p < a.P; ++p) {
+        uint32_t lo;
+        ok = granule_wait(own + (size_t)p * kArGranules, a.seq, a.timeout_ms, lo, a.err) && ok;
+        const uint32_t other = __shfl_xor(lo, 1, kWave);
+        sum += join_halves(lo, other);  // meaningful in even lanes
+    }
+    if (a.stats && t == 0) {
+        atomicAdd(a.stats + 2 * a.kind, wall_clock64() - tw0);
+        atomicAdd(a.stats + 2 * a.kind + 1, 1ull);
+    }
+    if (!(t & 1)) out[t >> 1] = sum;
+    if (!ok) raise_comm_error(a.err, 1 + a.kind, a.seq);
+}
 __device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const double *vals, int count, double *out)
 {
     const int t = threadIdx.x;
@@ -315,6 +350,12 @@ __device__ __forceinline__ double inv_norm(double nrm2)  // the VecScale guard o
 }
 __device__ __forceinline__ void givens_rider(const GivensRider &gr)
 {
+    // peer-store: the MAXPY launch only POSTED its ||w'||^2; the contributions are collected here, beside the row
+    // tiles -- nothing in a product on an un-normalised basis needs the norm, so this all-reduce costs no time
+    if (gr.ar.P) {
+        peer_allreduce_wait(gr.ar, 1, gr.nrm2);
+        __syncthreads();
+    }
     // un-normalised basis: the scale factor of the vector the MAXPY launch just wrote (its norm is all-reduced by now)
     // (nothing compounds: V~_j = w' of the product of the NORMALISED v_{j-1}, so ||V~_j|| = h_{j,j-1} <= ||K M^-1||)
     if (gr.sc && threadIdx.x == 0) gr.sc[gr.loc + 1] = inv_norm(*gr.nrm2);
@@ -427,6 +468,7 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
     }
 }
 
+void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t s);  // below
 static GivensRider no_rider()
 {
     GivensRider g{};
@@ -438,7 +480,7 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
           const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *od, const GivensRider *rider)
 {
     if (A.nrows == 0) {
-        if (rider) krylov_givens(rider->ka, rider->loc, rider->h, rider->nrm2, s);
+        if (rider) givens_rider_alone(*rider, done, s);
         return;
     }
     const int tpx = (A.ntiles + 7) / 8;
@@ -580,7 +622,7 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
                const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *odp, const GivensRider *rider)
 {
     if (A.nbrows == 0) {
-        if (rider) krylov_givens(rider->ka, rider->loc, rider->h, rider->nrm2, s);
+        if (rider) givens_rider_alone(*rider, done, s);
         return;
     }
     const int tpx = (A.ntiles + 7) / 8;
@@ -2328,6 +2370,15 @@ __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dot
 {
     givens_block(ka, loc, dots, nrm2);
 }
+__global__ __launch_bounds__(kThreads) void givens_rider_kernel(GivensRider gr, const int32_t *done)
+{
+    if (done && *done) return;
+    givens_rider(gr);
+}
+void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t s)  // a rank without rows: the rider without tiles
+{
+    hipLaunchKernelGGL(givens_rider_kernel, dim3(1), dim3(kThreads), 0, s, gr, done);
+}
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s)
 {
     hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2);
@@ -3161,13 +3212,11 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
             red[0] = tot;
         }
         __syncthreads();
-        if (b.ar.P) peer_allreduce_block(b.ar, red, 1, b.out);
+        // (un-normalised basis: the new vector's scale factor and the Givens step of this iteration ride in the product
+        // launch that follows (GivensRider); with ar_post_only that rider also collects the all-reduce posted here)
+        if (b.ar.P && b.ar_post_only) peer_allreduce_post(b.ar, red, 1);
+        else if (b.ar.P) peer_allreduce_block(b.ar, red, 1, b.out);
         else if (threadIdx.x == 0) b.out[0] = red[0];
-        if (b.sc) {
-            // un-normalised basis: the new vector's scale factor and the Givens step of this iteration ride in the
-            // product launch that follows (GivensRider) -- here they would be a serial tail of the whole launch, and
-            // would see the local norm when the all-reduce is a launch of its own
-        }
         return;
     }
     if (!is_main) {  // peer-store halo: unpack this rank's ghost rows (see fused_head_kernel)

@@ -1083,6 +1083,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     b.lam_in_dot = lam_in_dot;
                     b.partials = c->partials.p; b.out = nb; b.ar = ar2; b.err = c->errw.p; b.fin_ticks = c->fin_ticks;
                     b.sc = c->ba_sc.p; b.hbuf = sm2; b.ka = c->ka; b.loc = loc;
+                    // peer-store: ||w'||^2 is only POSTED here and collected by the rider of the product launch -- the
+                    // product of an un-normalised vector does not need it, so the link latency hides behind the row tiles
+                    const bool split = ar2.P && loc + 1 < mk;
+                    b.ar_post_only = split ? 1 : 0;
                     k::SendRanges sr = c->send_ranges;
                     const bool inb = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
                     if (sr.n > 0) b.sr = sr;
@@ -1090,7 +1094,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::iter_maxpy_uhead(b, s);
                     if (!ar2.P) c->comm->allreduce_sum(nb, 1, s);
                     // the Givens step of this iteration (and the new vector's scale factor) ride in the next product launch
-                    k::GivensRider gr{c->ka, loc, sm2, nb, c->ba_sc.p};
+                    k::GivensRider gr{c->ka, loc, sm2, nb, c->ba_sc.p, split ? ar2 : k::PeerAR{}};
                     if (loc + 1 < mk) product(Zj(loc + 1), Vj(loc + 2), inb, &gr);
                     else k::krylov_givens(c->ka, loc, sm2, nb, s);
                     last = -1;
