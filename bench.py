@@ -376,7 +376,7 @@ def main():
         # The kernel described is the one the timed loop LAUNCHES for the A block: y += A x on the fused
         # Schur path (y pre-loaded with B^T lambda: one more vector read), the plain product otherwise.
         "roofline": {"bound": "hbm",
-                     "kernel": ("spmv_bcsr_kernel" if spi["format"] != "csr" else "spmv_stream_kernel")
+                     "kernel": ({"csr": "spmv_stream_kernel", "bcsr2x2": "spmv_bcsr_kernel", "bcsr3x3": "spmv_bcsr3_kernel"}[spi["format"]])
                                + ("<.., ACC=true, RIDE=true>: y += A x, as launched by the fused Schur iteration "
                                   "(Givens rider in workgroup 0)" if in_solver_acc
                                   else "<.., ACC=false, RIDE=true>: y = A x, as launched by the iteration"),

@@ -313,8 +313,9 @@ int spk_get_spmv_info(const spk_ctx *c, int32_t *format, int64_t *layout_bytes)
     if (format) *format = c->spmv_format;
     if (layout_bytes) {
         const int64_t n = c->n_local;
-        *layout_bytes = c->spmv_format == 1 ? 36 * c->Ab.nblocks + 4 * ((int64_t)c->Ab.nbrows + 1) + 16 * n
-                                            : 12 * c->Ad.nnz + 4 * (n + 1) + 16 * n;
+        *layout_bytes = c->spmv_format == 1   ? 36 * c->Ab.nblocks + 4 * ((int64_t)c->Ab.nbrows + 1) + 16 * n
+                        : c->spmv_format == 2 ? 76 * c->Ab3.nblocks + 4 * ((int64_t)c->Ab3.nbrows + 1) + 16 * n
+                                              : 12 * c->Ad.nnz + 4 * (n + 1) + 16 * n;
     }
     return SPK_OK;
 }
@@ -490,7 +491,8 @@ int spk_time_spmv(spk_ctx *c, int warmup, int reps, double *ms_per_launch)
     SPK_HIP(hipEventCreate(&e0));
     SPK_HIP(hipEventCreate(&e1));
     auto one = [&]() {  // the kernel the solver launches for the A block
-        if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
+        if (c->spmv_format == 2) spk::k::spmv_bcsr3(c->Ab3, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
+        else if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
         else spk::k::spmv(c->Ad, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
     };
     for (int i = 0; i < warmup; ++i) one();
@@ -538,7 +540,8 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
             spk::k::GivensRider gr{c->ka, 0, c->small.p, c->small.p + 64, nullptr, spk::k::PeerAR{}};
             const spk::k::GivensRider *rp = c->kst.p ? &gr : nullptr;
             const bool acc = w == "spmv_acc";
-            if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
+            if (c->spmv_format == 2) spk::k::spmv_bcsr3(c->Ab3, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
+            else if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
             else spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
         }
         else if (w == "mult") spk::op_mult(c, x, y, nullptr);

@@ -115,6 +115,18 @@ struct BcsrDev {
     DevBuf<int32_t> ba_nbr, ba_wt;   // ba_wt[2 rho], [2 rho + 1] = its tiles [t0, t1)
 };
 
+// 3x3-blocked copy (dof-3 grids): one block column index per nine values; plane k (stride ldp) = entry (k / 3, k % 3) of
+// every block.  v32: the same planes in single precision for the FP32 inner sweeps (spk_pc_setup with inner sweeps).
+struct Bcsr3Dev {
+    int32_t nbrows = 0;
+    int64_t nblocks = 0, ldp = 0;
+    DevBuf<int32_t> browptr, bcol, tile_brow;
+    DevBuf<double> v;
+    DevBuf<float> v32;
+    int32_t ntiles = 0;
+    bool ok = false;
+};
+
 // Short-and-wide block (B: m rows x n_local cols) cut into column windows so
 // that x is streamed once for all m rows.
 struct WideDev {
@@ -341,6 +353,16 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
                const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr,
                const GivensRider *rider = nullptr);
 void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
+// ... and from the 3x3-blocked copy (same sums again)
+constexpr int kB3Tile = 256;  // blocks per tile: one per thread
+void spmv_bcsr3(const Bcsr3Dev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+                const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr,
+                const GivensRider *rider = nullptr);
+void build_b3tiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
+void bcsr3_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, int32_t *browptr, int32_t *bcol, double *v,
+                int64_t ldp, int32_t *fail, hipStream_t s);
+void jacobi_sweep_f32_b3(const Bcsr3Dev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                         const int32_t *done, hipStream_t s);
 // KSPSetOperators on the device: count off-rank entries per row, exclusive scan, split, 2x2 blocking
 void csr_count_off(const int32_t *rowptr, const int32_t *colidx, int nrows, int64_t lo, int64_t hi, int64_t ncols, int32_t *cnt,
                    int32_t *bad, hipStream_t s);
@@ -610,7 +632,8 @@ struct spk_ctx {
     // (0,0) block: diagonal part, compressed off-rank part
     spk::CsrDev Ad, Ao;
     spk::BcsrDev Ab;               // 2x2-blocked copy of Ad when the structure allows
-    int spmv_format = 0;           // 0 = CSR stream kernel, 1 = BCSR
+    int spmv_format = 0;           // 0 = CSR stream kernel, 1 = 2x2 blocks (Ab), 2 = 3x3 blocks (Ab3)
+    spk::Bcsr3Dev Ab3;             // 3x3-blocked copy (dof-3 grids)
     spk::DevBuf<int32_t> ao_rows;  // local row of each compressed Ao row
     spk::DevBuf<int32_t> ao_rowptr_full;  // Ao row pointers over all local rows (SpMV epilogue form)
     spk::k::SendRanges send_ranges{};     // halo rows as contiguous ranges, when they are

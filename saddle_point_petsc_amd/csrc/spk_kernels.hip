@@ -646,6 +646,140 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
 }
 
 // ---------------------------------------------------------------------------
+// 3x3-blocked stream SpMV (dof-3 grids: BASELINE config 5's 3-D hexahedra, 81 stored entries per row).
+// One block column index per NINE values (8.44 B per stored non-zero against 12 in CSR); the values sit in nine
+// planes, plane k = entry (k / 3, k % 3) of every block, so consecutive lanes read consecutive doubles of a plane.
+// One block per thread: its nine products land in LDS as (a00 x0, a01 x1, a02 x2, a10 x0, ...); row 3 br + r then
+// adds its triples in block order = CSR order: bit-identical to the CSR kernel and the oracle.
+// ---------------------------------------------------------------------------
+void build_b3tiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow)
+{
+    tile_brow.clear();
+    tile_brow.push_back(0);
+    int32_t r = 0;
+    while (r < nbrows) {
+        const int32_t r0 = r;
+        while (r < nbrows && (r - r0) < kThreads / 3 && (browptr[r + 1] - browptr[r0]) <= kB3Tile) ++r;
+        if (r == r0) ++r;  // block row longer than a tile: strided path
+        tile_brow.push_back(r);
+    }
+}
+
+template <bool ACC, bool RIDE>
+__global__ __launch_bounds__(kThreads) void spmv_bcsr3_kernel(
+    const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol, const double *__restrict__ v, int64_t ldp,
+    const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd, const double *__restrict__ x,
+    double *__restrict__ y, const int32_t *__restrict__ bt_rowptr, const int32_t *__restrict__ bt_colidx,
+    const double *__restrict__ bt_val, const double *__restrict__ lam, OffDiag od, const int32_t *__restrict__ done,
+    GivensRider gr)
+{
+    if (done && *done) return;
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles
+        givens_rider(gr);
+        return;
+    }
+    const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
+    const int t = (bx & 7) * tiles_per_xcd + (bx >> 3);
+    if (t >= ntiles) return;
+    __shared__ double prod[kB3Tile * 9];
+    const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
+    const int b0 = browptr[br0], b1 = browptr[br1];
+    const int cnt = b1 - b0;
+
+    if (cnt > kB3Tile) {
+        // one very long block row: strided partial sums, tree order
+        double a[3] = {0.0, 0.0, 0.0};
+        for (int q = b0 + threadIdx.x; q < b1; q += kThreads) {
+            const int c = bcol[q];
+            const double x0 = x[3 * (int64_t)c], x1 = x[3 * (int64_t)c + 1], x2 = x[3 * (int64_t)c + 2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                a[r] += v[(3 * r) * ldp + q] * x0 + v[(3 * r + 1) * ldp + q] * x1 + v[(3 * r + 2) * ldp + q] * x2;
+        }
+        __shared__ double red[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double sw = wave_sum(a[r]);
+            if ((threadIdx.x & 63) == 0) red[4 * r + (threadIdx.x >> 6)] = sw;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int r = 3 * br0 + threadIdx.x;
+            double o = ((red[4 * threadIdx.x] + red[4 * threadIdx.x + 1]) + red[4 * threadIdx.x + 2]) + red[4 * threadIdx.x + 3];
+            if (od.rowptr)
+                for (int k = od.rowptr[r]; k < od.rowptr[r + 1]; ++k) o += od.val[k] * od.xg[od.colidx[k]];
+            if (bt_rowptr)
+                for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) o += bt_val[k] * lam[bt_colidx[k]];
+            if (ACC) o += y[r];
+            y[r] = o;
+        }
+        return;
+    }
+
+    const int q = threadIdx.x;
+    if (q < cnt) {
+        const int c = __builtin_nontemporal_load(bcol + b0 + q);
+        double a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = __builtin_nontemporal_load(v + k * ldp + b0 + q);
+        const double x0 = x[3 * (int64_t)c], x1 = x[3 * (int64_t)c + 1], x2 = x[3 * (int64_t)c + 2];
+        double *p = prod + 9 * q;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            p[3 * r] = a[3 * r] * x0;
+            p[3 * r + 1] = a[3 * r + 1] * x1;
+            p[3 * r + 2] = a[3 * r + 2] * x2;
+        }
+    }
+    __syncthreads();
+
+    const int lr = threadIdx.x;  // local row
+    if (lr < 3 * (br1 - br0)) {
+        const int br = br0 + lr / 3, rr = lr % 3;
+        const int k0 = browptr[br] - b0, k1 = browptr[br + 1] - b0;
+        double s = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            const double *p = prod + 9 * k + 3 * rr;
+            s += p[0];
+            s += p[1];
+            s += p[2];
+        }
+        const int r = 3 * br0 + lr;
+        if (od.rowptr)  // off-rank columns of this row (ghost values already exchanged)
+            for (int k = od.rowptr[r]; k < od.rowptr[r + 1]; ++k) s += od.val[k] * od.xg[od.colidx[k]];
+        if (bt_rowptr)
+            for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
+        if (ACC) s += y[r];
+        y[r] = s;
+    }
+}
+
+void spmv_bcsr3(const Bcsr3Dev &A, const double *x, double *y, const CsrDev *bt, const double *lam,
+                const int32_t *done, hipStream_t s, bool accumulate, const OffDiag *odp, const GivensRider *rider)
+{
+    if (A.nbrows == 0) {
+        if (rider) givens_rider_alone(*rider, done, s);
+        return;
+    }
+    const int tpx = (A.ntiles + 7) / 8;
+    const OffDiag od = odp ? *odp : OffDiag{nullptr, nullptr, nullptr, nullptr};
+    const GivensRider gr = rider ? *rider : no_rider();
+    const int nride = rider ? 1 : 0;
+#define SPK_LAUNCH_B3(ACC, RIDE)                                                                                          \
+    hipLaunchKernelGGL((spmv_bcsr3_kernel<ACC, RIDE>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
+                       A.v.p, A.ldp, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,                    \
+                       bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
+    if (accumulate) {
+        if (rider) SPK_LAUNCH_B3(true, true);
+        else SPK_LAUNCH_B3(true, false);
+    } else {
+        if (rider) SPK_LAUNCH_B3(false, true);
+        else SPK_LAUNCH_B3(false, false);
+    }
+#undef SPK_LAUNCH_B3
+}
+
+// ---------------------------------------------------------------------------
 // KSPSetOperators on the device (set-up must not dwarf the solve).  The caller's CSR slab is
 // uploaded once as it is; what MatMPIAIJ does at assembly time -- the split into a diagonal block with local
 // column numbers and an off-rank block -- and the 2x2 blocking run here, one thread per (block) row, entry
@@ -827,6 +961,55 @@ void bcsr_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, 
 {
     hipLaunchKernelGGL(bcsr_fill_kernel, dim3((nbr + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, rp, ci, va, nbr, browptr,
                        bcol, vtop, vbot, fail);
+}
+
+// Same for 3 x 3 blocks: rows 3 br .. 3 br + 2 hold the same number of entries, a multiple of three, in column triples
+// (3c, 3c+1, 3c+2) that agree between the three rows; block q of the row starts at rowptr[3 br] / 9.  Values go to nine
+// planes of stride ldp (plane k = entry (k / 3, k % 3)).
+__global__ __launch_bounds__(kThreads) void bcsr3_fill_kernel(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                              const double *__restrict__ va, int nbr, int32_t *__restrict__ browptr,
+                                                              int32_t *__restrict__ bcol, double *__restrict__ v, int64_t ldp,
+                                                              int32_t *__restrict__ fail)
+{
+    const int br = blockIdx.x * kThreads + threadIdx.x;
+    if (br > nbr) return;
+    if (br == nbr) {
+        browptr[br] = rp[3 * nbr] / 9;
+        return;
+    }
+    const int r = 3 * br;
+    const int k0 = rp[r], k1 = rp[r + 1], k2 = rp[r + 2], k3 = rp[r + 3];
+    const int len = k1 - k0;
+    if ((k2 - k1) != len || (k3 - k2) != len || (len % 3) || (k0 % 9)) {
+        *fail = 1;
+        return;
+    }
+    browptr[br] = k0 / 9;
+    int64_t q = k0 / 9;
+    for (int k = 0; k < len; k += 3, ++q) {
+        const int c0 = ci[k0 + k];
+        bool ok = (c0 % 3) == 0;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int base = k0 + rr * len + k;
+            ok = ok && ci[base] == c0 && ci[base + 1] == c0 + 1 && ci[base + 2] == c0 + 2;
+        }
+        if (!ok) {
+            *fail = 1;
+            return;
+        }
+        bcol[q] = c0 / 3;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[(3 * rr + j) * ldp + q] = va[k0 + rr * len + k + j];
+    }
+}
+void bcsr3_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, int32_t *browptr, int32_t *bcol, double *v,
+                int64_t ldp, int32_t *fail, hipStream_t s)
+{
+    hipLaunchKernelGGL(bcsr3_fill_kernel, dim3((nbr + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, s, rp, ci, va, nbr, browptr,
+                       bcol, v, ldp, fail);
 }
 
 // ---------------------------------------------------------------------------
@@ -1879,6 +2062,75 @@ void jacobi_sweep_f32(const CsrDev &A, const float *val32, const float *d32, flo
     const int tpx = (A.ntiles + 7) / 8;
     hipLaunchKernelGGL(jacobi_sweep_f32_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.rowptr.p, A.colidx.p, val32,
                        A.tile_row.p, A.ntiles, tpx, d32, omega, x32, yin, yout, done);
+}
+
+// The same sweep from the 3x3-blocked copy with single-precision planes (4.44 B per stored non-zero against 8):
+// products rounded once each, summed per row in block order = CSR order -- the same bits as the CSR sweep and the oracle.
+__global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_b3_kernel(
+    const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol, const float *__restrict__ v32, int64_t ldp,
+    const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd, const float *__restrict__ d32, float omega,
+    const float *__restrict__ x32, const float *__restrict__ yin, float *__restrict__ yout, const int32_t *__restrict__ done)
+{
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own (the oracle's float loop)
+    if (done && *done) return;
+    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    __shared__ float prod[kB3Tile * 9];
+    const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
+    const int b0 = browptr[br0], b1 = browptr[br1];
+    const int cnt = b1 - b0;
+    if (cnt > kB3Tile) {  // one block row longer than a tile: its three rows by three threads, CSR order
+        if (threadIdx.x < 3) {
+            const int rr = threadIdx.x, r = 3 * br0 + rr;
+            float s = 0.0f;
+            for (int q = b0; q < b1; ++q) {
+                const int c = bcol[q];
+                s = (s + (v32[(3 * rr) * ldp + q] * yin[3 * (int64_t)c]));
+                s = (s + (v32[(3 * rr + 1) * ldp + q] * yin[3 * (int64_t)c + 1]));
+                s = (s + (v32[(3 * rr + 2) * ldp + q] * yin[3 * (int64_t)c + 2]));
+            }
+            yout[r] = yin[r] + ((omega * d32[r]) * (x32[r] - s));
+        }
+        return;
+    }
+    const int q = threadIdx.x;
+    if (q < cnt) {
+        const int c = __builtin_nontemporal_load(bcol + b0 + q);
+        float a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = __builtin_nontemporal_load(v32 + k * ldp + b0 + q);
+        const float y0 = yin[3 * (int64_t)c], y1 = yin[3 * (int64_t)c + 1], y2 = yin[3 * (int64_t)c + 2];
+        float *p = prod + 9 * q;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            p[3 * r] = (a[3 * r] * y0);
+            p[3 * r + 1] = (a[3 * r + 1] * y1);
+            p[3 * r + 2] = (a[3 * r + 2] * y2);
+        }
+    }
+    __syncthreads();
+    const int lr = threadIdx.x;
+    if (lr < 3 * (br1 - br0)) {
+        const int br = br0 + lr / 3, rr = lr % 3;
+        const int k0 = browptr[br] - b0, k1 = browptr[br + 1] - b0;
+        float s = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+            const float *p = prod + 9 * k + 3 * rr;
+            s = (s + p[0]);
+            s = (s + p[1]);
+            s = (s + p[2]);
+        }
+        const int r = 3 * br0 + lr;
+        yout[r] = yin[r] + ((omega * d32[r]) * (x32[r] - s));
+    }
+}
+void jacobi_sweep_f32_b3(const Bcsr3Dev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                         const int32_t *done, hipStream_t s)
+{
+    if (A.nbrows == 0) return;
+    const int tpx = (A.ntiles + 7) / 8;
+    hipLaunchKernelGGL(jacobi_sweep_f32_b3_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, A.v32.p, A.ldp,
+                       A.tile_brow.p, A.ntiles, tpx, d32, omega, x32, yin, yout, done);
 }
 
 // rows with off-rank columns: y[row] -= omega d (Ao_row . ghost values of the previous iterate)

@@ -382,8 +382,45 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
                 Ab.browptr.release(); Ab.bcol.release(); Ab.vtop.release(); Ab.vbot.release();
             }
         }
+        // 3x3-blocked copy for dof-3 grids (the 3-D generator: 81 entries per row in 27 blocks), same verification
+        Bcsr3Dev &A3 = c->Ab3;
+        A3.ok = false;
+        A3.nbrows = 0;
+        A3.ntiles = 0;
+        A3.v32.release();
+        if (!Ab.ok && n % 3 == 0 && n > 0 && nnzd % 9 == 0) {
+            const int32_t nbr = n / 3;
+            const int64_t nb = nnzd / 9;
+            A3.ldp = (nb + 1 + 7) & ~(int64_t)7;
+            A3.browptr.alloc_raw((size_t)nbr + 1, 8);
+            A3.bcol.alloc_raw((size_t)nb, 16);
+            A3.v.alloc_raw((size_t)(9 * A3.ldp), 32);
+            SPK_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t) * 4, s));
+            k::bcsr3_fill(Ad.rowptr.p, Ad.colidx.p, Ad.val.p, nbr, A3.browptr.p, A3.bcol.p, A3.v.p, A3.ldp, flags.p, s);
+            SPK_HIP(hipMemcpyAsync(hflags, flags.p, sizeof hflags, hipMemcpyDeviceToHost, s));
+            SPK_HIP(hipStreamSynchronize(s));
+            if (!hflags[0]) {
+                HostBuf<int32_t> brp;
+                brp.alloc((size_t)nbr + 1);
+                parallel_for((int64_t)nbr + 1, [&](int64_t b0, int64_t b1, int) {
+                    for (int64_t br = b0; br < b1; ++br) brp[(size_t)br] = drp[(size_t)(3 * br)] / 9;
+                });
+                std::vector<int32_t> tb;
+                k::build_b3tiles(brp.data(), nbr, tb);
+                A3.nbrows = nbr;
+                A3.nblocks = nb;
+                A3.ntiles = (int32_t)tb.size() - 1;
+                A3.tile_brow.upload(tb.data(), tb.size(), 8);
+                A3.ok = true;
+            } else {
+                A3.browptr.release(); A3.bcol.release(); A3.v.release();
+            }
+        } else {
+            A3.browptr.release(); A3.bcol.release(); A3.v.release();
+        }
         const char *fmt = getenv("SPK_SPMV_FORMAT");
-        c->spmv_format = (Ab.ok && !(fmt && !strcmp(fmt, "csr"))) ? 1 : 0;
+        const bool csr_forced = fmt && !strcmp(fmt, "csr");
+        c->spmv_format = csr_forced ? 0 : (Ab.ok ? 1 : (A3.ok ? 2 : 0));
     }
     } catch (const Error &e) {
         local = e;
@@ -688,7 +725,8 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool h
     }
     const k::OffDiag od = c->offdiag();
     const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;   // off-rank columns in the same kernel
-    if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
+    if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
+    else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
     else k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
     if (m > 0) {
         apply_B(c, x, nullptr, y + nl, done);
@@ -756,13 +794,20 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     }
     // FP32 copies for the inner solve
     c->a32.release(); c->d32.release(); c->x32.release(); c->y32a.release(); c->y32b.release();
-    if (c->inner_sweeps > 0) {
+    c->Ab3.v32.release();
+    if (c->inner_sweeps > 0 && c->spmv_format == 2) {   // the sweeps read the 3x3-blocked planes in single precision
+        c->Ab3.v32.alloc_raw((size_t)(9 * c->Ab3.ldp), 32);
+        k::cvt_vals_f32(c->Ab3.v.p, c->Ab3.v32.p, 9 * c->Ab3.ldp, s);
+    }
+    if (c->inner_sweeps > 0 && c->spmv_format != 2) {
         c->a32.alloc((size_t)c->Ad.nnz, 32);
+        k::cvt_vals_f32(c->Ad.val.p, c->a32.p, c->Ad.nnz, s);
+    }
+    if (c->inner_sweeps > 0) {
         c->d32.alloc((size_t)c->n_local, 8);
         c->x32.alloc((size_t)c->n_local, 8);
         c->y32a.alloc((size_t)c->n_local, 8);
         c->y32b.alloc((size_t)c->n_local, 8);
-        k::cvt_vals_f32(c->Ad.val.p, c->a32.p, c->Ad.nnz, s);
         k::cvt_vals_f32(c->dinv.p, c->d32.p, c->n_local, s);
     }
     // dense rows of B D for the fused path (Schur LOWER/FULL, even local size)
@@ -808,7 +853,8 @@ static void inner_apply(spk_ctx *c, const double *x, double *y, int mode, const 
             k::gather_f32(ya, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
             c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
         }
-        k::jacobi_sweep_f32(c->Ad, c->a32.p, c->d32.p, om, c->x32.p, ya, yb, done, s);
+        if (c->spmv_format == 2) k::jacobi_sweep_f32_b3(c->Ab3, c->d32.p, om, c->x32.p, ya, yb, done, s);
+        else k::jacobi_sweep_f32(c->Ad, c->a32.p, c->d32.p, om, c->x32.p, ya, yb, done, s);
         if (c->n_ghost > 0) k::sweep_offdiag_f32(c->Ao, c->ao_rows.p, c->d32.p, om, c->xghost.p, yb, done, s);
         std::swap(ya, yb);
     }
@@ -1046,7 +1092,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     }
                     const k::OffDiag od = c->offdiag();
                     const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;
-                    if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
+                    if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
+                    else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
                     else k::spmv(c->Ad, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
                 };
                 if (loc == 0) {
@@ -1230,7 +1277,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     if (!packed) k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
                 }
-                if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
+                if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
+                else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
                 else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
             } else if (fusedj) {
                 bool inhead = prev_inhead;

@@ -179,7 +179,7 @@ class Context:
     def spmv_info(self):
         fmt, b = C.c_int32(), C.c_int64()
         lib.spk_get_spmv_info(self.h, C.byref(fmt), C.byref(b))
-        return dict(format={0: "csr", 1: "bcsr2x2"}[fmt.value], layout_bytes=b.value)
+        return dict(format={0: "csr", 1: "bcsr2x2", 2: "bcsr3x3"}[fmt.value], layout_bytes=b.value)
 
     def _n(self):
         s = self.sizes()

@@ -921,8 +921,8 @@ def test_row_partitioned_fp32_inner_solve(spk, oracle):
 
 
 def test_3d_grid_config5_shape(spk, oracle):
-    """BASELINE config 5 in miniature: 3-D grid (build-defined generator), dof 3 (81 entries per row:
-    no 2x2 blocks -> CSR stream kernel), halo-exchange SpMV over 2 z-slabs, FGMRES with the mixed
+    """BASELINE config 5 in miniature: 3-D grid (build-defined generator), dof 3 (81 entries per row in
+    27 blocks of 3 x 3 -> the 3x3-blocked kernels), halo-exchange SpMV over 2 z-slabs, FGMRES with the mixed
     FP32 inner solve, and the six-row saddle system on one rank."""
     mx, my, mz = 10, 9, 12
     A, f = spk.AssembleOperator_Laplace3D(mx, my, mz)
@@ -933,9 +933,12 @@ def test_3d_grid_config5_shape(spk, oracle):
     rhs = np.concatenate([f, g])
     with spk.Context(0) as c:
         c.set_block(spk.BLOCK_A00, A)
-        assert c.spmv_info()["format"] == "csr"
+        assert c.spmv_info()["format"] == "bcsr3x3"
+        assert c.spmv_info()["layout_bytes"] < 0.75 * (12 * A.nnz + 4 * (A.nrows + 1) + 16 * A.nrows)
         assert np.array_equal(c.mult(x), oracle.spmv(Ao, x))                      # bitwise
         c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.8)
+        # the FP32 sweeps from the single-precision planes: the oracle's float loop, bit for bit
+        assert np.array_equal(c.pc_apply(x), oracle.pc_apply_inner(Ao, None, oracle.PC_JACOBI, 0, 3, 0.8, x))
         u, info = c.fgmres(f, rtol=1e-9)
         uo, io = oracle.fgmres(Ao, f, pc_type=oracle.PC_JACOBI, rtol=1e-9, inner_its=3, inner_omega=0.8)
         assert info["reason"] == 2 and abs(info["its"] - io["its"]) <= 1 and relerr(u, uo) < 1e-7
