@@ -75,7 +75,8 @@ enum { SPK_CONVERGED_RTOL = 2, SPK_CONVERGED_ATOL = 3, SPK_CONVERGED_ITS = 4,
  * exposes through KSPSetFromOptions (SaddlePointProblem.c:67).  Fill with
  * spk_default_opts() first (PETSc defaults). */
 typedef struct spk_opts {
-    int32_t restart;        /* -ksp_gmres_restart            (30)    */
+    int32_t restart;        /* -ksp_gmres_restart            (30); 1..1022 -- up to 62 on the fused kernels, beyond
+                               on the step-by-step path (Gram-Schmidt in chunks of 40 vectors) */
     int32_t max_it;         /* -ksp_max_it                   (10000) */
     double rtol;            /* -ksp_rtol                     (1e-5)  */
     double abstol;          /* -ksp_atol                     (1e-50) */

@@ -294,7 +294,8 @@ struct KrylovState {
 
 // kernel launch wrappers (spk_kernels.hip)
 namespace k {
-constexpr int kMaxNv = 64;       // max vectors in one mdot/maxpy launch (restart <= 63)
+constexpr int kMaxNv = 64;       // max vectors in one mdot/maxpy launch; restart <= 62 takes the fused kernels
+constexpr int kBigNv = 1024;     // restart lengths up to kBigNv - 2 run Gram-Schmidt in chunks of <= 40 vectors
 constexpr int kPartialLd = 64;   // leading dimension of block partials
 constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
 constexpr int kBTile = 512;      // 2x2 blocks per tile of the blocked SpMV kernels
@@ -603,7 +604,8 @@ void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double
                 int64_t nl, int m, double *z, double *c, double *w1side, const double *wl_in, double *wl_out,
                 const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *sr = nullptr,
                 int bd_packed = 0);
-void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc = nullptr);  // sc: y_i *= sc[i] (un-normalised Z)
+// sc: y_i *= sc[i] (un-normalised Z); restart > kMaxNv - 2: the triangle stays in global memory
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc = nullptr, int restart = 0);
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)
 void krylov_refine_decide(const KrylovArrays &ka, int loc, int mode, const double *dots, const double *nrm2,
@@ -669,6 +671,7 @@ struct spk_ctx {
     int inner_sweeps = 0;
     double inner_omega = 1.0;
     spk::DevBuf<float> a32, d32, x32, y32a, y32b;
+    spk::DevBuf<double> bigdots;   // Gram-Schmidt coefficients of restart lengths beyond the fused kernels' 62
 
     // scratch
     spk::DevBuf<double> partials;  // kMaxBlocks * kPartialLd

@@ -2530,9 +2530,12 @@ void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t 
 // iteration (done, skip_iter) are not stored here but handed back as gate[0], gate[1]; the caller
 // stores them once no workgroup of ITS launch can still be about to read them (kernel A of the
 // two-launch iteration: its workgroups must all take the same branch, they feed one reduction).
-__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
+// CAP: capacity of the LDS staging (restart + 2); the fused kernels carry the small instance, restart lengths beyond
+// kMaxNv - 2 take the stand-alone kernel with the large one (krylov_givens)
+template <int CAP>
+__device__ void givens_block_t(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
 {
-    __shared__ double Hc[kMaxNv + 2], Hr[kMaxNv + 2], ccs[kMaxNv + 2], sss[kMaxNv + 2], sc[4];
+    __shared__ double Hc[CAP], Hr[CAP], ccs[CAP], sss[CAP], sc[4];
     KrylovState *st = ka.st;
     if (st->done || st->skip_iter) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
@@ -2618,9 +2621,18 @@ __device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots
     }
 }
 
+__device__ void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
+{
+    givens_block_t<kMaxNv + 2>(ka, loc, dots, nrm2, gate);
+}
+
 __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
 {
     givens_block(ka, loc, dots, nrm2);
+}
+__global__ __launch_bounds__(256) void krylov_givens_big_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)
+{
+    givens_block_t<kBigNv + 2>(ka, loc, dots, nrm2, nullptr);
 }
 __global__ __launch_bounds__(kThreads) void givens_rider_kernel(GivensRider gr, const int32_t *done)
 {
@@ -2633,7 +2645,8 @@ void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t 
 }
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s)
 {
-    hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2);
+    if (loc + 2 > kMaxNv + 2) hipLaunchKernelGGL(krylov_givens_big_kernel, dim3(1), dim3(256), 0, s, ka, loc, dots, nrm2);
+    else hipLaunchKernelGGL(krylov_givens_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, nrm2);
 }
 
 // Head of a fused Schur iteration (one pass over the new basis vector):
@@ -4127,9 +4140,40 @@ __global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka, 
     // (un-normalised Z~_k of the BA iteration: x += sum y_k sc_k Z~_k)
     for (int k = 0; k < n; ++k) ka.nrs[k] = sc ? ys[k] * sc[k] : ys[k];
 }
-void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc)
+// The same back substitution for restart lengths whose triangle does not fit LDS (-ksp_gmres_restart > 62): one thread,
+// same order of operations, H read from global memory eight entries at a time (the loads do not depend on the chain)
+__global__ __launch_bounds__(64) void krylov_cycle_end_big_kernel(KrylovArrays ka)
 {
-    hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka, sc);
+    __shared__ double ys[kBigNv + 2];
+    if (threadIdx.x != 0) return;
+    KrylovState *st = ka.st;
+    const int n = st->loc_done, ldh = ka.ldh;
+    for (int k = n - 1; k >= 0; --k) {
+        double t = ka.rs[k];
+        int j = k + 1;
+        for (; j + 8 <= n; j += 8) {
+            double h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = ka.H[(size_t)ldh * (j + u) + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t -= h[u] * ys[j + u];
+        }
+        for (; j < n; ++j) t -= ka.H[(size_t)ldh * j + k] * ys[j];
+        const double piv = ka.H[(size_t)ldh * k + k];
+        if (piv == 0.0) {
+            if (st->reason >= 0) st->reason = SPK_DIVERGED_BREAKDOWN;
+            st->done = 1;
+            st->loc_done = 0;
+            return;
+        }
+        ys[k] = t / piv;
+    }
+    for (int k = 0; k < n; ++k) ka.nrs[k] = ys[k];
+}
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc, int restart)
+{
+    if (restart > kMaxNv - 2) hipLaunchKernelGGL(krylov_cycle_end_big_kernel, dim3(1), dim3(64), 0, s, ka);
+    else hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka, sc);
 }
 
 }  // namespace k

@@ -935,7 +935,7 @@ static void ensure_krylov(spk_ctx *c, const spk_opts &o)
     c->ensure_scratch();
     c->ensure_vectors();
     const int mk = o.restart;
-    if (mk < 1 || mk > k::kMaxNv - 2) fail(SPK_ERR_ARG, "fgmres: restart %d outside [1,%d]", mk, k::kMaxNv - 2);
+    if (mk < 1 || mk > k::kBigNv - 2) fail(SPK_ERR_ARG, "fgmres: restart %d outside [1,%d]", mk, k::kBigNv - 2);
     const int32_t hist_cap = (int32_t)std::min<int64_t>((int64_t)std::max(o.max_it, 0) + 2, 1 << 22);
     if (c->ws_restart != mk) {
         // one more of each than the cycle uses: the un-normalised three-launch form lets the last iteration of a cycle
@@ -1008,13 +1008,19 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
 
     // fused Schur path: VecScale + PC + B^T part of the operator in one pass ("head"), B D w' in the
     // MAXPY pass, the Givens step of iteration j-1 inside the head kernel of iteration j
-    const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR;
+    // -ksp_gmres_restart beyond 62: the step-by-step path, Gram-Schmidt in chunks of <= 40 vectors (the fused kernels
+    // keep one lane / one LDS slot per basis vector)
+    const bool big = mk > k::kMaxNv - 2;
+    if (big && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine != SPK_REFINE_NEVER)
+        fail(SPK_ERR_UNSUPPORTED, "fgmres: -ksp_gmres_cgs_refinement_type needs restart <= %d (restart %d)", k::kMaxNv - 2, mk);
+    if (big && c->bigdots.n < (size_t)mk + 4) c->bigdots.alloc((size_t)mk + 4);
+    const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR && !big;
     const int m = c->m;
     const int32_t nl = c->n_local;
     // the same head kernel without a constraint block: Jacobi on K = A (the reference as written,
     // SaddlePointProblem.c:66, and BASELINE config 2): VecScale + PCApply_Jacobi + deferred Givens
     const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && nl % 2 == 0 && nl > 0 &&
-                        c->inner_sweeps == 0;
+                        c->inner_sweeps == 0 && !big;
     const bool head = fused || fusedj;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
     const int bpk = fused && c->bd_packed ? 1 : 0;   // B D as m/2 parity-interleaved planes
@@ -1081,7 +1087,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         for (int loc = 0; loc < mk && !stop; ++loc) {
             const int32_t *done = &c->kst.p->skip_iter;  // the gate of everything inside an iteration
             double *w = Vj(loc + 1);
-            double *db = dotsbuf(loc), *nb = nrmbuf(loc);
+            double *db = big ? c->bigdots.p : dotsbuf(loc), *nb = nrmbuf(loc);
             if (ba || un3) {
                 // the product K z~ of a vector (halo, then diagonal and off-rank columns in one kernel), either format
                 auto product = [&](const double *zvec, double *wvec, bool halo_done, const k::GivensRider *rider = nullptr) {
@@ -1329,6 +1335,19 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     head_done = false;
                     last = loc;
                 }
+            } else if (big) {
+                // classical Gram-Schmidt in chunks: every inner product is taken with the SAME w before any update
+                for (int v0 = 0; v0 <= loc; v0 += 40) {
+                    const int cnt = std::min(40, loc + 1 - v0);
+                    k::mdot(Vj(v0), ld, cnt, w, N, n_dot, c->fin(db + v0), done, s);
+                }
+                c->comm->allreduce_sum(db, loc + 2, s);
+                for (int v0 = 0; v0 <= loc; v0 += 40) {
+                    const int cnt = std::min(40, loc + 1 - v0);
+                    const bool lastc = v0 + 40 > loc;
+                    k::maxpy(Vj(v0), ld, cnt, nullptr, db + v0, -1.0, w, N, n_dot, c->fin(lastc ? nb : nullptr), done, s);
+                }
+                c->comm->allreduce_sum(nb, nn, s);
             } else {
                 // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
                 // across ranks the all-reduces ride in the finish of the two kernels (peer-store backend)
@@ -1365,7 +1384,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
         if (head && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
-        k::krylov_cycle_end(c->ka, s, (ba || un3) ? c->ba_sc.p : nullptr);
+        k::krylov_cycle_end(c->ka, s, (ba || un3) ? c->ba_sc.p : nullptr, mk);
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);

@@ -266,6 +266,32 @@ def test_restart_lengths(spk, oracle, restart, single):
     assert r == pytest.approx(info["rnorm"], rel=1e-6)      # the recurrence estimate is the true residual
 
 
+@pytest.mark.parametrize("restart,orthog", [(63, 0), (100, 0), (200, 1), (500, 0)])
+def test_long_restart_cycles(spk, oracle, restart, orthog):
+    """-ksp_gmres_restart beyond the 62 of the fused kernels (PETSc takes any length through KSPSetFromOptions,
+    SaddlePointProblem.c:67): the step-by-step path with Gram-Schmidt in chunks of 40 vectors, the Givens step and the
+    back substitution from their large forms.  One cycle can hold the whole solve here (restart 500 > iterations)."""
+    A, f = spk.AssembleOperator_Laplace(24, 20)
+    B, g = spk.AssembleOperator_Constraints(24, 20)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x, info = c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=4000, orthog=orthog)
+        if orthog == 0:
+            with pytest.raises(spk.SpkError):      # the refinement passes exist for restart <= 62 only: refused, not ignored
+                c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=10, cgs_refine=2)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, restart=restart, rtol=1e-10, max_it=4000,
+                           orthog=orthog)
+    assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 2
+    k = min(len(info["history"]), len(io["history"]), 150) - 1
+    assert np.allclose(info["history"][:k], io["history"][:k], rtol=1e-5)
+    assert relerr(x, xo) < 1e-7
+    r = np.linalg.norm(rhs - oracle.apply_K(A, B, x))
+    assert r <= 1.01e-10 * np.linalg.norm(rhs) and r == pytest.approx(info["rnorm"], rel=1e-4)
+
+
 def test_single_reduction_jacobi_head_path(spk, oracle):
     """The same single-reduction route on the Jacobi head path (K = A, the reference as written):
     ||w'||^2 = w.w - |h|^2, MAXPY + VecScale + PCApply_Jacobi + Givens in one launch."""
