@@ -131,7 +131,23 @@ def main():
     ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="opts.iteration_form: 0 auto, 1 four launches per iteration, 2 two launches, 3 three launches")
     ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
+    ap.add_argument("--watchdog", type=float, default=900.0, help="seconds after which a run that is still going says WHERE it "
+                                                                  "is stuck (rank, phase) on stderr and exits 4; 0: off")
     args = ap.parse_args()
+
+    # A multi-GPU run that hangs (a rendezvous, a collective of the fallback backend) would otherwise end in the
+    # launcher's kill with nothing to read: the watchdog names the rank and the phase it never left.
+    phase = ["start"]
+
+    def watchdog():
+        time.sleep(args.watchdog)
+        print(f"[bench] watchdog: rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} still in phase "
+              f"'{phase[0]}' after {args.watchdog:.0f} s -- giving up", file=sys.stderr, flush=True)
+        os._exit(4)
+
+    if args.watchdog > 0:
+        import threading
+        threading.Thread(target=watchdog, daemon=True).start()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +169,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        phase[0] = "torch.distributed rendezvous"
         import torch
         import torch.distributed as dist
         if os.environ.get("SPK_BENCH_COMM") == "gloo":
@@ -164,6 +181,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    phase[0] = "host assembly"
     import saddle_point_petsc_amd as S   # fails loudly if libspk.so is not built
 
     M = args.grid
@@ -192,6 +210,7 @@ def main():
     ctx = S.Context(local_rank)     # HIP runtime start-up + stream + scratch: per process, not per KSPSetOperators
     t_ctx = time.time() - t_ctx
     t_up = time.time()
+    phase[0] = "communicator set-up (RCCL unique id, init)"
     if use_dist and os.environ.get("SPK_BENCH_COMM") == "gloo":
         ctx.comm_init_torch(dist, rank, world)
     elif use_dist:
@@ -202,11 +221,14 @@ def main():
         # Krylov all-reduces and halo rows written straight into the peers' HBM over xGMI by the
         # solver's kernels; falls back (collectively) to the communicator above when a rank cannot
         # map a peer's window
+        phase[0] = "peer-store windows (HIP IPC mapping, self-test)"
         if not ctx.comm_enable_peer() and rank == 0:
             print(f"[bench] peer-store collectives off ({ctx.last_error()}); using {ctx.comm_backend()}", file=sys.stderr)
+    phase[0] = "KSPSetOperators (upload, split, halo plan)"
     ctx.set_block(S.BLOCK_A00, A)
     if saddle:
         ctx.set_block(S.BLOCK_A10, B)
+    phase[0] = "KSPSetUp (preconditioner)"
     pc = S.PC_JACOBI if not saddle else S.PC_SCHUR
     fact = {"schur-full": S.SCHUR_FULL, "schur-lower": S.SCHUR_LOWER, "schur-upper": S.SCHUR_UPPER,
             "schur-diag": S.SCHUR_DIAG, "jacobi": S.SCHUR_FULL}[args.pc]
@@ -245,10 +267,13 @@ def main():
         return el, inf
 
     # ---- warm-up: W untimed iterations
+    phase[0] = "warm-up solve"
     if args.warmup > 0:
         ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
     # ---- timed: exactly K iterations
+    phase[0] = "timed solve"
     elapsed, info = timed_solve(args.steps, **kw)
+    phase[0] = "post-solve checks (true residual, full cycles, kernel timings)"
 
     # ---- integrity of the timed solve (every N): the residual norm the device carries through its
     # Givens recurrence must equal the TRUE residual ||b - K x|| recomputed from the iterate with one
@@ -414,6 +439,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of PETSc's algorithm; PETSc itself is not
     # installable here) on a bounded sample of the SAME workload, all host cores.
+    phase[0] = "cpu baseline (oracle)"
     if world == 1 and not args.no_cpu_baseline:
         import oracle as O
         cores = host_cores()
