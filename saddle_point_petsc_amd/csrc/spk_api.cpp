@@ -1,6 +1,6 @@
 // spk_api.cpp -- the extern "C" surface declared in include/spk.h.
 // Argument checks, error capture (exceptions never cross the ABI), staging of
-// host vectors.  The work is in spk_solver.cpp / spk_kernels.hip.
+// host vectors.  The work is in spk_solver.cpp / spk_k_*.hip.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>

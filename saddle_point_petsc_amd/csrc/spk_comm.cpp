@@ -5,7 +5,7 @@
 //   * VecScatter of the ghost entries MatMult_MPIAIJ needs (the two slab neighbours)
 // Backends:
 //   PeerComm   production: windows of the peers' HBM mapped through HIP IPC, the solver's own
-//              kernels store tagged 8-byte granules into them over xGMI (spk_kernels.hip);
+//              kernels store tagged 8-byte granules into them over xGMI (spk_device.hpp);
 //              wraps one of the backends below for set-up traffic and as the fallback
 //   RcclComm   one process per GPU: ncclAllReduce / grouped ncclSend+ncclRecv on the solver's
 //              stream, ncclAllGather for set-up (RCCL is dlopen'ed so that the library loads,
@@ -322,7 +322,7 @@ private:
 
 // ---------------------------------------------------------------------------
 // Peer-store backend: one-shot all-reduce and halo exchange written straight into
-// the peers' memory over xGMI by the solver's own kernels (spk_kernels.hip, "granules").
+// the peers' memory over xGMI by the solver's own kernels (spk_device.hpp, "granules").
 // Each rank owns two windows of UNCACHED device memory, mapped into every peer
 // through HIP IPC (ranks in other processes) or used directly (logical ranks of one
 // process): the all-reduce window (fixed size) and the halo staging (sized by the

@@ -4,7 +4,9 @@
 //   spk_api.cpp      C ABI entry points, argument checks, error strings
 //   spk_solver.cpp   device-resident FGMRES: the host only ENQUEUES a restart
 //                    cycle; Hessenberg/Givens/convergence live on the device
-//   spk_kernels.hip  hand-written gfx950 kernels (HBM-bound, FP64, no MFMA)
+//   spk_k_*.hip      hand-written gfx950 kernels (HBM-bound, FP64, no MFMA): spmv (+ set-up, FP32 sweeps), vec (MDot,
+//                    MAXPY, PC pieces), krylov (scalar work, head kernels), iter (fused iteration), comm (peer-store
+//                    launches); spk_device.hpp = the device helpers they share
 //   spk_comm.cpp     collectives: peer-store windows over xGMI on top of RCCL (one process per
 //                    GPU); host-callback and in-process backends for 1-GPU rehearsals
 //   spk_partition.cpp host-only row-slab split + halo plan
@@ -138,7 +140,7 @@ struct WideDev {
 };
 
 // ---------------------------------------------------------------------------
-// peer-store windows (one-shot collectives over xGMI, spk_comm.cpp / spk_kernels.hip)
+// peer-store windows (one-shot collectives over xGMI, spk_comm.cpp / spk_device.hpp, spk_k_comm.hip)
 // ---------------------------------------------------------------------------
 namespace k {
 struct SendRanges;
@@ -292,7 +294,7 @@ struct KrylovState {
     double tt;
 };
 
-// kernel launch wrappers (spk_kernels.hip)
+// kernel launch wrappers (spk_k_*.hip)
 namespace k {
 constexpr int kMaxNv = 64;       // max vectors in one mdot/maxpy launch; restart <= 62 takes the fused kernels
 constexpr int kBigNv = 1024;     // restart lengths up to kBigNv - 2 run Gram-Schmidt in chunks of <= 40 vectors
@@ -301,14 +303,14 @@ constexpr int kMaxBlocks = 2048; // cap for grid-stride vector kernels
 constexpr int kBTile = 512;      // 2x2 blocks per tile of the blocked SpMV kernels
 
 void build_tiles(const int32_t *rowptr, int32_t nrows, std::vector<int32_t> &tile_row);
-// arms the block-partials buffer of the cross-workgroup finish (spk_kernels.hip)
+// arms the block-partials buffer of the cross-workgroup finish (spk_k_vec.hip)
 void arm_partials(double *p, size_t n, hipStream_t s);
 // test hook: a reduction with a partial that never arrives (see spk_debug_finish_timeout)
 struct Finish;
 void finish_probe(const Finish &f, hipStream_t s);
 
 // where a reducing kernel leaves its result: block partials (armed with the sentinel of the
-// "last block reduces" protocol, spk_kernels.hip) and the output slot
+// "last block reduces" protocol, spk_device.hpp) and the output slot
 struct Finish {
     double *partials;
     double *out;
@@ -465,7 +467,7 @@ struct GivensRider {
     double *sc;      // un-normalised basis: sc[loc + 1] = 1 / sqrt(*nrm2) is set first (nullptr: not)
     PeerAR ar;       // P != 0: *nrm2 is first collected from the peers (the MAXPY launch posted its contribution)
 };
-// ---- two-launch iteration (spk_kernels.hip, "Two-launch iteration") ----
+// ---- two-launch iteration (spk_k_iter.hip, "Two-launch iteration") ----
 // kernel A: w = s (A z~ + c~), v and z normalised on the way, h = V^T w and q = B D w from the tile epilogues
 struct IterA {
     // 2x2-blocked matrix and its tiling
