@@ -537,7 +537,7 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
         else if (w == "spmv_acc" || w == "spmv_ride") {
             // y += A x (spmv_ride: y = A x) in the active format, as the default iteration launches it: with the Givens
             // rider in workgroup 0 once a solve has left its state behind (the rider finds `done` set and leaves)
-            spk::k::GivensRider gr{c->ka, 0, c->small.p, c->small.p + 64, nullptr, spk::k::PeerAR{}};
+            spk::k::GivensRider gr{c->ka, 0, c->small.p, c->small.p + 64, nullptr, nullptr, 0, spk::k::FinErr{nullptr, 0}, spk::k::PeerAR{}};
             const spk::k::GivensRider *rp = c->kst.p ? &gr : nullptr;
             const bool acc = w == "spmv_acc";
             if (c->spmv_format == 2) spk::k::spmv_bcsr3(c->Ab3, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);

@@ -105,12 +105,7 @@ __device__ __forceinline__ bool arrive_last(unsigned nblocks)
 // when everything has arrived), then a fixed binary tree; the result is valid in LDS scratch[0..k)
 // after return.  scratch: T doubles.
 constexpr int kFinBatch = 16;  // partials a reducer thread requests together (registers of the WHOLE kernel: 32 cost 2x the VGPRs)
-// where a reducer reports a partial that never arrived (execution failure, not a numerical one): the
-// context's sticky error word; the bound of the wait in 100 MHz ticks
-struct FinErr {
-    int32_t *err;
-    uint32_t ticks;
-};
+// (FinErr -- where a reducer reports a partial that never arrived -- is declared in spk_internal.hpp)
 __device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, int k, double *scratch, FinErr fe)
 {
     const int T = blockDim.x;
@@ -225,41 +220,6 @@ __device__ __forceinline__ double join_halves(uint32_t lo, uint32_t hi)
 // adjacent lanes) sum vals[0..count) over the ranks into out[0..count): every rank adds the
 // P contributions in rank order, its own included, so all ranks hold the same bits.
 // No barrier inside; vals may be LDS or global, out may alias vals.
-// The two halves of peer_allreduce_block, for a sum whose consumer sits in a LATER launch: `post` (threads
-// 0 .. 2*count-1) stores this rank's contribution into every rank's window and returns; `wait` (same threads, any
-// later launch of the stream) collects the P contributions.  What runs between the two overlaps the link latency.
-__device__ __forceinline__ void peer_allreduce_post(const PeerAR &a, const double *vals, int count)
-{
-    const int t = threadIdx.x;
-    if (t >= 2 * count) return;
-    const int slot = (int)(a.seq & (kArSlots - 1));
-    const uint32_t half = reinterpret_cast<const uint32_t *>(vals)[t];
-    const unsigned long long g = ((unsigned long long)a.seq << 32) | half;
-    const size_t mine = ((size_t)slot * a.P + a.me) * kArGranules + t;
-    for (int p = 0; p < a.P; ++p) st_sys(a.win[p] + mine, g);
-}
-__device__ __forceinline__ void peer_allreduce_wait(const PeerAR &a, int count, double *out)
-{
-    const int t = threadIdx.x;
-    if (t >= 2 * count) return;
-    const int slot = (int)(a.seq & (kArSlots - 1));
-    const unsigned long long *own = a.win[a.me] + (size_t)slot * a.P * kArGranules + t;
-    const unsigned long long tw0 = (a.stats && t == 0) ? wall_clock64() : 0ull;
-    double sum = 0.0;
-    bool ok = true;
-    for (int p = 0; p < a.P; ++p) {
-        uint32_t lo;
-        ok = granule_wait(own + (size_t)p * kArGranules, a.seq, a.timeout_ms, lo, a.err) && ok;
-        const uint32_t other = __shfl_xor(lo, 1, kWave);
-        sum += join_halves(lo, other);  // meaningful in even lanes
-    }
-    if (a.stats && t == 0) {
-        atomicAdd(a.stats + 2 * a.kind, wall_clock64() - tw0);
-        atomicAdd(a.stats + 2 * a.kind + 1, 1ull);
-    }
-    if (!(t & 1)) out[t >> 1] = sum;
-    if (!ok) raise_comm_error(a.err, 1 + a.kind, a.seq);
-}
 __device__ __forceinline__ void peer_allreduce_block(const PeerAR &a, const double *vals, int count, double *out)
 {
     const int t = threadIdx.x;
@@ -415,10 +375,21 @@ __device__ __forceinline__ double inv_norm(double nrm2)  // the VecScale guard o
 }
 __device__ __forceinline__ void givens_rider(const GivensRider &gr)
 {
-    // peer-store: the MAXPY launch only POSTED its ||w'||^2; the contributions are collected here, beside the row
-    // tiles -- nothing in a product on an un-normalised basis needs the norm, so this all-reduce costs no time
-    if (gr.ar.P) {
-        peer_allreduce_wait(gr.ar, 1, gr.nrm2);
+    // The MAXPY launch left ||w'||^2 as one partial per workgroup (IterB::defer_fin): reduced here, in the fixed order,
+    // and all-reduced across ranks (peer-store) -- beside the row tiles, since nothing in a product on an un-normalised
+    // basis needs the norm: neither the reduction tail nor the link latency is on the critical path
+    if (gr.fin_n > 0) {
+        __shared__ double red[kThreads];
+        final_reduce(gr.fin_partials, gr.fin_n, kPartialLd, 1, red, gr.fe);
+        if (threadIdx.x == 0) {
+            double *slot = gr.fin_partials + (size_t)gr.fin_n * kPartialLd;  // the multiplier entries' share
+            const double lam2 = peek(slot);
+            publish(slot, __longlong_as_double((long long)kSentinelBits));   // re-armed for the next user of the row
+            red[0] = red[0] + lam2;
+        }
+        __syncthreads();
+        if (gr.ar.P) peer_allreduce_block(gr.ar, red, 1, gr.nrm2);
+        else if (threadIdx.x == 0) gr.nrm2[0] = red[0];
         __syncthreads();
     }
     // un-normalised basis: the scale factor of the vector the MAXPY launch just wrote (its norm is all-reduced by now)

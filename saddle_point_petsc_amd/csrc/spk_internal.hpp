@@ -455,6 +455,12 @@ struct KrylovArrays {
     int32_t hist_cap, ldh;
     int32_t tentative;  // 1: the recurrence may end a cycle, only a true residual may end the solve
 };
+// where a reducer reports a partial that never arrived (execution failure, not a numerical one): the
+// context's sticky error word; the bound of the wait in 100 MHz ticks
+struct FinErr {
+    int32_t *err;
+    uint32_t ticks;
+};
 // The Givens step of iteration `loc` (Hessenberg column h[0..loc], ||w'||^2 in *nrm2), carried by workgroup 0 of a
 // product launch: the serial chain runs beside the row tiles instead of at the tail of the MAXPY launch's reducer.
 // The tiles of that launch read the gate words BEFORE the step may set them (they compute a product nobody uses when
@@ -465,7 +471,12 @@ struct GivensRider {
     const double *h;
     double *nrm2;
     double *sc;      // un-normalised basis: sc[loc + 1] = 1 / sqrt(*nrm2) is set first (nullptr: not)
-    PeerAR ar;       // P != 0: *nrm2 is first collected from the peers (the MAXPY launch posted its contribution)
+    // fin_n > 0: *nrm2 is first REDUCED here from the fin_n partial rows the MAXPY launch published (+ the row behind
+    // them: the multiplier entries' share), then all-reduced across ranks when ar.P != 0
+    double *fin_partials;
+    int32_t fin_n;
+    FinErr fe;
+    PeerAR ar;
 };
 // ---- two-launch iteration (spk_k_iter.hip, "Two-launch iteration") ----
 // kernel A: w = s (A z~ + c~), v and z normalised on the way, h = V^T w and q = B D w from the tile epilogues
@@ -538,7 +549,7 @@ struct IterB {
     double *sc, *hbuf, *wl_out;
     KrylovArrays ka;
     int loc;
-    int ar_post_only;    // peer-store: only POST ||w'||^2 (that rider collects the sum: peer_allreduce_post / _wait)
+    int defer_fin;       // publish the partials of ||w'||^2 and leave: the rider of the next product launch reduces them
 };
 // dots = false: the SpMV / normalisation part alone (three-launch form; one tile per workgroup: slots = tiles_per_xcd)
 void iter_spmv_mdot(const IterA &a, hipStream_t s, bool dots = true);
@@ -587,7 +598,7 @@ struct IterBA {
 void iter_ba(const IterBA &p, hipStream_t s);
 // block-column range of every tile of the blocked matrix (set-up of the BA kernel's neighbour lists)
 void tile_col_range(const int32_t *browptr, const int32_t *bcol, const int32_t *tile_brow, int ntiles, int32_t *out, hipStream_t s);
-void iter_maxpy_uhead(IterB b, hipStream_t s);
+int iter_maxpy_uhead(IterB b, hipStream_t s);   // returns the number of partial rows (GivensRider::fin_n)
 int iter_slots(int tiles_per_xcd, int wg_per_cu);
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
 void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0,

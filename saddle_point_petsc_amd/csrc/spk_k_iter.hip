@@ -418,17 +418,20 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
             if (b.sc) b.wl_out[r] = w1;
         }
         __syncthreads();
-        final_reduce(b.partials, gmain, kPartialLd, 1, red, FinErr{b.err, b.fin_ticks});
-        if (threadIdx.x == 0) {
-            double tot = red[0];
-            for (int r = 0; r < m; ++r) tot += b.lam_in_dot ? wraws[r] * wraws[r] : 0.0;
-            red[0] = tot;
+        double lam2 = 0.0;  // the multiplier entries' share of ||w'||^2 (rank 0 only)
+        if (threadIdx.x == 0)
+            for (int r = 0; r < m; ++r) lam2 += b.lam_in_dot ? wraws[r] * wraws[r] : 0.0;
+        if (b.defer_fin) {
+            // un-normalised basis: nothing in the product launch that follows needs ||w'||^2 except its rider workgroup
+            // (scale factor, Givens step), so the rider also REDUCES the partials (and all-reduces the sum) beside the
+            // row tiles: this launch ends with its last streaming workgroup -- no publish -> re-read tail
+            if (threadIdx.x == 0) publish(b.partials + (size_t)gmain * kPartialLd, lam2);
+            return;
         }
+        final_reduce(b.partials, gmain, kPartialLd, 1, red, FinErr{b.err, b.fin_ticks});
+        if (threadIdx.x == 0) red[0] = red[0] + lam2;
         __syncthreads();
-        // (un-normalised basis: the new vector's scale factor and the Givens step of this iteration ride in the product
-        // launch that follows (GivensRider); with ar_post_only that rider also collects the all-reduce posted here)
-        if (b.ar.P && b.ar_post_only) peer_allreduce_post(b.ar, red, 1);
-        else if (b.ar.P) peer_allreduce_block(b.ar, red, 1, b.out);
+        if (b.ar.P) peer_allreduce_block(b.ar, red, 1, b.out);
         else if (threadIdx.x == 0) b.out[0] = red[0];
         return;
     }
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(T) void iter_maxpy_uhead_kernel(IterB b)
     }
 }
 
-void iter_maxpy_uhead(IterB b, hipStream_t s)
+int iter_maxpy_uhead(IterB b, hipStream_t s)   // returns the number of partial rows its norm is spread over (defer_fin)
 {
     const int64_t n2 = b.nl / 2;
     // thin workgroups below 0.5 M entries (as MAXPY), fat ones above
@@ -627,6 +630,7 @@ void iter_maxpy_uhead(IterB b, hipStream_t s)
     else SPK_IB_MP(8);
 #undef SPK_IB_MP
 #undef SPK_IB
+    return b.gmain;
 }
 
 // ---------------------------------------------------------------------------

@@ -1136,18 +1136,20 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     b.lam_in_dot = lam_in_dot;
                     b.partials = c->partials.p; b.out = nb; b.ar = ar2; b.err = c->errw.p; b.fin_ticks = c->fin_ticks;
                     b.sc = c->ba_sc.p; b.hbuf = sm2; b.ka = c->ka; b.loc = loc;
-                    // peer-store: ||w'||^2 is only POSTED here and collected by the rider of the product launch -- the
-                    // product of an un-normalised vector does not need it, so the link latency hides behind the row tiles
-                    const bool split = ar2.P && loc + 1 < mk;
-                    b.ar_post_only = split ? 1 : 0;
+                    // ||w'||^2 is left as one partial per workgroup: the rider of the product launch reduces it (and all-reduces
+                    // it, peer-store) beside the row tiles -- the product of an un-normalised vector does not need the norm.
+                    // (Not with an all-reduce that is a launch of its own, nor behind the last iteration of a cycle.)
+                    const bool defer = loc + 1 < mk && (c->comm->size() == 1 || ar2.P);
+                    b.defer_fin = defer ? 1 : 0;
                     k::SendRanges sr = c->send_ranges;
                     const bool inb = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
                     if (sr.n > 0) b.sr = sr;
                     b.done = done;
-                    k::iter_maxpy_uhead(b, s);
-                    if (!ar2.P) c->comm->allreduce_sum(nb, 1, s);
+                    const int fin_n = k::iter_maxpy_uhead(b, s);
+                    if (!ar2.P && !defer) c->comm->allreduce_sum(nb, 1, s);
                     // the Givens step of this iteration (and the new vector's scale factor) ride in the next product launch
-                    k::GivensRider gr{c->ka, loc, sm2, nb, c->ba_sc.p, split ? ar2 : k::PeerAR{}};
+                    k::GivensRider gr{c->ka, loc, sm2, nb, c->ba_sc.p, defer ? c->partials.p : nullptr, defer ? fin_n : 0,
+                                      k::FinErr{c->errw.p, c->fin_ticks}, defer ? ar2 : k::PeerAR{}};
                     if (loc + 1 < mk) product(Zj(loc + 1), Vj(loc + 2), inb, &gr);
                     else k::krylov_givens(c->ka, loc, sm2, nb, s);
                     last = -1;
