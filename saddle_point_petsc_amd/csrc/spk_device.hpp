@@ -274,10 +274,12 @@ __device__ __forceinline__ int converged_default(double rnorm, const KrylovState
 // two-launch iteration: its workgroups must all take the same branch, they feed one reduction).
 // CAP: capacity of the LDS staging (restart + 2); the fused kernels carry the small instance, restart lengths beyond
 // kMaxNv - 2 take the stand-alone kernel with the large one (krylov_givens)
-template <int CAP>
-__device__ void givens_block_t(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
+// lds: 4 * cap + 4 doubles of LDS scratch (the caller's own staging where it has any: a rider workgroup of a product
+// launch uses the tile's product buffer, so the launch needs no LDS beyond what its row tiles need)
+__device__ inline void givens_block_lds(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate,
+                                        double *lds, int cap)
 {
-    __shared__ double Hc[CAP], Hr[CAP], ccs[CAP], sss[CAP], sc[4];
+    double *Hc = lds, *Hr = lds + cap, *ccs = lds + 2 * cap, *sss = lds + 3 * cap, *sc = lds + 4 * cap;
     KrylovState *st = ka.st;
     if (st->done || st->skip_iter) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
@@ -363,6 +365,12 @@ __device__ void givens_block_t(const KrylovArrays &ka, int loc, const double *do
     }
 }
 
+template <int CAP>
+__device__ void givens_block_t(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
+{
+    __shared__ double lds[4 * CAP + 4];
+    givens_block_lds(ka, loc, dots, nrm2, gate, lds, CAP);
+}
 __device__ inline void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate = nullptr)
 {
     givens_block_t<kMaxNv + 2>(ka, loc, dots, nrm2, gate);
@@ -373,13 +381,14 @@ __device__ __forceinline__ double inv_norm(double nrm2)  // the VecScale guard o
     const double tt = sqrt(nrm2);
     return tt > 1e-300 ? 1.0 / tt : 1.0;
 }
-__device__ __forceinline__ void givens_rider(const GivensRider &gr)
+// lds: >= kThreads + 4 * (kMaxNv + 2) + 4 doubles of the calling workgroup's LDS
+__device__ __forceinline__ void givens_rider(const GivensRider &gr, double *lds)
 {
     // The MAXPY launch left ||w'||^2 as one partial per workgroup (IterB::defer_fin): reduced here, in the fixed order,
     // and all-reduced across ranks (peer-store) -- beside the row tiles, since nothing in a product on an un-normalised
     // basis needs the norm: neither the reduction tail nor the link latency is on the critical path
     if (gr.fin_n > 0) {
-        __shared__ double red[kThreads];
+        double *red = lds;
         final_reduce(gr.fin_partials, gr.fin_n, kPartialLd, 1, red, gr.fe);
         if (threadIdx.x == 0) {
             double *slot = gr.fin_partials + (size_t)gr.fin_n * kPartialLd;  // the multiplier entries' share
@@ -395,7 +404,7 @@ __device__ __forceinline__ void givens_rider(const GivensRider &gr)
     // un-normalised basis: the scale factor of the vector the MAXPY launch just wrote (its norm is all-reduced by now)
     // (nothing compounds: V~_j = w' of the product of the NORMALISED v_{j-1}, so ||V~_j|| = h_{j,j-1} <= ||K M^-1||)
     if (gr.sc && threadIdx.x == 0) gr.sc[gr.loc + 1] = inv_norm(*gr.nrm2);
-    givens_block(gr.ka, gr.loc, gr.h, gr.nrm2);
+    givens_block_lds(gr.ka, gr.loc, gr.h, gr.nrm2, nullptr, lds + kThreads, kMaxNv + 2);
 }
 
 void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t s);  // spk_k_krylov.hip

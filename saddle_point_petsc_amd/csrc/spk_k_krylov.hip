@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void krylov_givens_big_kernel(KrylovArrays ka,
 __global__ __launch_bounds__(kThreads) void givens_rider_kernel(GivensRider gr, const int32_t *done)
 {
     if (done && *done) return;
-    givens_rider(gr);
+    __shared__ double lds[kThreads + 4 * (kMaxNv + 2) + 4];
+    givens_rider(gr, lds);
 }
 void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t s)  // a rank without rows: the rider without tiles
 {

@@ -42,8 +42,9 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
     const int32_t *__restrict__ done, GivensRider gr)
 {
     if (done && *done) return;
-    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles
-        givens_rider(gr);
+    __shared__ double prod[TILE + 8];
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles (its LDS: the product buffer)
+        givens_rider(gr, prod);
         return;
     }
     // workgroups b, b+8, ... share an XCD (round-robin dispatch): give each XCD
@@ -52,7 +53,6 @@ __global__ __launch_bounds__(T) void spmv_stream_kernel(
     const int t = (bx & 7) * tiles_per_xcd + (bx >> 3);
     if ((bx >> 3) >= tiles_per_xcd || t >= ntiles) return;
 
-    __shared__ double prod[TILE + 8];
     const int r0 = tile_row[t], r1 = tile_row[t + 1];
     const int nz0 = rowptr[r0], nz1 = rowptr[r1];
     const int a0 = nz0 & ~3;
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const double *__restrict__ lam, OffDiag od, const int32_t *__restrict__ done, GivensRider gr)
 {
     if (done && *done) return;
-    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles
-        givens_rider(gr);
+    __shared__ double prod[kBTile * 4];
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles (its LDS: the product buffer)
+        givens_rider(gr, prod);
         return;
     }
     const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
     const int t = (bx & 7) * tiles_per_xcd + (bx >> 3);
     if (t >= ntiles) return;
-    __shared__ double prod[kBTile * 4];
     const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
     const int b0 = browptr[br0], b1 = browptr[br1];
     const int cnt = b1 - b0;
@@ -321,14 +321,14 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr3_kernel(
     GivensRider gr)
 {
     if (done && *done) return;
-    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles
-        givens_rider(gr);
+    __shared__ double prod[kB3Tile * 9];
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the tiles (its LDS: the product buffer)
+        givens_rider(gr, prod);
         return;
     }
     const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
     const int t = (bx & 7) * tiles_per_xcd + (bx >> 3);
     if (t >= ntiles) return;
-    __shared__ double prod[kB3Tile * 9];
     const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
     const int b0 = browptr[br0], b1 = browptr[br1];
     const int cnt = b1 - b0;
