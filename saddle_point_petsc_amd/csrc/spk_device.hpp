@@ -106,6 +106,8 @@ __device__ __forceinline__ bool arrive_last(unsigned nblocks)
 // after return.  scratch: T doubles.
 constexpr int kFinBatch = 16;  // partials a reducer thread requests together (registers of the WHOLE kernel: 32 cost 2x the VGPRs)
 // (FinErr -- where a reducer reports a partial that never arrived -- is declared in spk_internal.hpp)
+// FB: partials a reducer thread requests together (kFinBatch; 2 where the caller's kernel must stay small in registers)
+template <int FB = kFinBatch>
 __device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, int k, double *scratch, FinErr fe)
 {
     const int T = blockDim.x;
@@ -115,8 +117,8 @@ __device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, i
     const double armed = __longlong_as_double((long long)kSentinelBits);
     double acc = 0.0;
     if (i < k) {
-        for (int b0 = sl; b0 < nb; b0 += nsl * kFinBatch) {
-            double v[kFinBatch];
+        for (int b0 = sl; b0 < nb; b0 += nsl * FB) {
+            double v[FB];
             // the whole batch is requested at once (one round trip) and simply requested again while
             // any of its slots is still armed, i.e. its workgroup has not published yet
             const unsigned long long t0 = wall_clock64();
@@ -124,12 +126,12 @@ __device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, i
             do {
                 armed_seen = false;
 #pragma unroll
-                for (int u = 0; u < kFinBatch; ++u) {
+                for (int u = 0; u < FB; ++u) {
                     const int b = b0 + u * nsl;
                     v[u] = b < nb ? peek(partials + (size_t)b * ld + i) : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < kFinBatch; ++u) armed_seen = armed_seen || is_sentinel(v[u]);
+                for (int u = 0; u < FB; ++u) armed_seen = armed_seen || is_sentinel(v[u]);
                 if (armed_seen) __builtin_amdgcn_s_sleep(1);
             } while (armed_seen && wall_clock64() - t0 < (unsigned long long)fe.ticks);  // default 4 s at 100 MHz
             // a slot still armed after the bound: its workgroup never published (never dispatched, or the
@@ -137,7 +139,7 @@ __device__ __forceinline__ void final_reduce(double *partials, int nb, int ld, i
             // the host turns it into SPK_ERR_HIP and re-arms the whole buffer before the next use
             if (armed_seen && fe.err) __hip_atomic_store(fe.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int u = 0; u < kFinBatch; ++u) {
+            for (int u = 0; u < FB; ++u) {
                 const int b = b0 + u * nsl;
                 if (b < nb) publish(partials + (size_t)b * ld + i, armed);  // re-arm for the next launch
                 acc += v[u];
@@ -276,6 +278,10 @@ __device__ __forceinline__ int converged_default(double rnorm, const KrylovState
 // kMaxNv - 2 take the stand-alone kernel with the large one (krylov_givens)
 // lds: 4 * cap + 4 doubles of LDS scratch (the caller's own staging where it has any: a rider workgroup of a product
 // launch uses the tile's product buffer, so the launch needs no LDS beyond what its row tiles need)
+// LEAN: loops kept rolled -- the step then fits 32 VGPRs, which is what a rider workgroup of the SpMV kernels may use
+// without raising the register allocation of every row-tile wave of the launch (measured: 64 instead of 32 allocated
+// VGPRs cost the 1024^2 product 5 us of 62); the serial chain takes ~1 us longer, beside the row tiles
+template <bool LEAN = false>
 __device__ inline void givens_block_lds(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate,
                                         double *lds, int cap)
 {
@@ -314,10 +320,19 @@ __device__ inline void givens_block_lds(const KrylovArrays &ka, int loc, const d
     // serial chain is two FMAs per step (LDS round trips per step cost ~3 us at loc = 30, on the
     // critical path of the head kernel this step rides in)
     double run = Hc[0];
-    for (int j = 1; j <= loc; ++j) {
-        const double h1 = Hc[j], cj = ccs[j - 1], sj = sss[j - 1];
-        Hr[j - 1] = cj * run + sj * h1;
-        run = cj * h1 - sj * run;
+    if constexpr (LEAN) {
+#pragma unroll 1
+        for (int j = 1; j <= loc; ++j) {
+            const double h1 = Hc[j], cj = ccs[j - 1], sj = sss[j - 1];
+            Hr[j - 1] = cj * run + sj * h1;
+            run = cj * h1 - sj * run;
+        }
+    } else {
+        for (int j = 1; j <= loc; ++j) {
+            const double h1 = Hc[j], cj = ccs[j - 1], sj = sss[j - 1];
+            Hr[j - 1] = cj * run + sj * h1;
+            run = cj * h1 - sj * run;
+        }
     }
     Hr[loc] = run;
     Hr[loc + 1] = tt;
@@ -342,7 +357,12 @@ __device__ inline void givens_block_lds(const KrylovArrays &ka, int loc, const d
     } else {
         rnorm = 0.0;
     }
-    for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hr[j];
+    if constexpr (LEAN) {
+#pragma unroll 1
+        for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hr[j];
+    } else {
+        for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hr[j];
+    }
     st->its += 1;
     st->loc_done = loc + 1;
     st->rnorm = rnorm;
@@ -369,7 +389,7 @@ template <int CAP>
 __device__ void givens_block_t(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate)
 {
     __shared__ double lds[4 * CAP + 4];
-    givens_block_lds(ka, loc, dots, nrm2, gate, lds, CAP);
+    givens_block_lds<false>(ka, loc, dots, nrm2, gate, lds, CAP);
 }
 __device__ inline void givens_block(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate = nullptr)
 {
@@ -389,7 +409,7 @@ __device__ __forceinline__ void givens_rider(const GivensRider &gr, double *lds)
     // basis needs the norm: neither the reduction tail nor the link latency is on the critical path
     if (gr.fin_n > 0) {
         double *red = lds;
-        final_reduce(gr.fin_partials, gr.fin_n, kPartialLd, 1, red, gr.fe);
+        final_reduce<2>(gr.fin_partials, gr.fin_n, kPartialLd, 1, red, gr.fe);
         if (threadIdx.x == 0) {
             double *slot = gr.fin_partials + (size_t)gr.fin_n * kPartialLd;  // the multiplier entries' share
             const double lam2 = peek(slot);
@@ -404,7 +424,7 @@ __device__ __forceinline__ void givens_rider(const GivensRider &gr, double *lds)
     // un-normalised basis: the scale factor of the vector the MAXPY launch just wrote (its norm is all-reduced by now)
     // (nothing compounds: V~_j = w' of the product of the NORMALISED v_{j-1}, so ||V~_j|| = h_{j,j-1} <= ||K M^-1||)
     if (gr.sc && threadIdx.x == 0) gr.sc[gr.loc + 1] = inv_norm(*gr.nrm2);
-    givens_block_lds(gr.ka, gr.loc, gr.h, gr.nrm2, nullptr, lds + kThreads, kMaxNv + 2);
+    givens_block_lds<true>(gr.ka, gr.loc, gr.h, gr.nrm2, nullptr, lds + kThreads, kMaxNv + 2);
 }
 
 void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t s);  // spk_k_krylov.hip
