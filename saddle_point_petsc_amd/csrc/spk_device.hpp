@@ -281,23 +281,52 @@ __device__ __forceinline__ int converged_default(double rnorm, const KrylovState
 // LEAN: loops kept rolled -- the step then fits 32 VGPRs, which is what a rider workgroup of the SpMV kernels may use
 // without raising the register allocation of every row-tile wave of the launch (measured: 64 instead of 32 allocated
 // VGPRs cost the 1024^2 product 5 us of 62); the serial chain takes ~1 us longer, beside the row tiles
+// What the step reads that does NOT depend on the norm (the Hessenberg column, the stored rotations, rs[loc], the gate
+// words), requested by the lanes that will stage it: a caller with work of its own between the request and the use (the
+// rider's reduction) overlaps the two round trips.  loc <= blockDim.x - 1 (the small instance: restart <= 62).
+struct GivensPre {
+    double h, c, s, rs;
+    int go;   // 0: the solve / cycle is over (uniform)
+};
+__device__ __forceinline__ GivensPre givens_prefetch(const KrylovArrays &ka, int loc, const double *dots)
+{
+    GivensPre p{0.0, 0.0, 0.0, 0.0, 0};
+    const KrylovState *st = ka.st;
+    p.go = !(st->done || st->skip_iter);
+    if ((int)threadIdx.x <= loc) {
+        p.h = dots[threadIdx.x];
+        p.c = ka.cc[threadIdx.x];
+        p.s = ka.ss[threadIdx.x];
+    }
+    if (threadIdx.x == 33) p.rs = ka.rs[loc];
+    return p;
+}
 template <bool LEAN = false>
 __device__ inline void givens_block_lds(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, int *gate,
-                                        double *lds, int cap)
+                                        double *lds, int cap, const GivensPre *pre = nullptr)
 {
     double *Hc = lds, *Hr = lds + cap, *ccs = lds + 2 * cap, *sss = lds + 3 * cap, *sc = lds + 4 * cap;
     KrylovState *st = ka.st;
-    if (st->done || st->skip_iter) return;  // uniform: read before anyone writes it
+    if (pre ? !pre->go : (st->done || st->skip_iter)) return;  // uniform: read before anyone writes it
     const int ldh = ka.ldh;
     double *Hg = ka.H + (size_t)ldh * loc;  // column loc
     // every global value the serial chain needs is fetched here, in parallel, once
-    for (int j = threadIdx.x; j <= loc; j += blockDim.x) {
-        Hc[j] = dots[j];
-        ccs[j] = ka.cc[j];
-        sss[j] = ka.ss[j];
+    if (pre) {
+        if ((int)threadIdx.x <= loc) {
+            Hc[threadIdx.x] = pre->h;
+            ccs[threadIdx.x] = pre->c;
+            sss[threadIdx.x] = pre->s;
+        }
+        if (threadIdx.x == 33) sc[1] = pre->rs;
+    } else {
+        for (int j = threadIdx.x; j <= loc; j += blockDim.x) {
+            Hc[j] = dots[j];
+            ccs[j] = ka.cc[j];
+            sss[j] = ka.ss[j];
+        }
+        if (threadIdx.x == 33) sc[1] = ka.rs[loc];
     }
     if (threadIdx.x == 32) sc[0] = *nrm2;
-    if (threadIdx.x == 33) sc[1] = ka.rs[loc];
     __syncthreads();
     if (threadIdx.x != 0) return;
     const double rs_loc = sc[1];
@@ -321,7 +350,7 @@ __device__ inline void givens_block_lds(const KrylovArrays &ka, int loc, const d
     // critical path of the head kernel this step rides in)
     double run = Hc[0];
     if constexpr (LEAN) {
-#pragma unroll 1
+#pragma unroll 2
         for (int j = 1; j <= loc; ++j) {
             const double h1 = Hc[j], cj = ccs[j - 1], sj = sss[j - 1];
             Hr[j - 1] = cj * run + sj * h1;
@@ -407,12 +436,15 @@ __device__ __forceinline__ void givens_rider(const GivensRider &gr, double *lds)
     // The MAXPY launch left ||w'||^2 as one partial per workgroup (IterB::defer_fin): reduced here, in the fixed order,
     // and all-reduced across ranks (peer-store) -- beside the row tiles, since nothing in a product on an un-normalised
     // basis needs the norm: neither the reduction tail nor the link latency is on the critical path
+    // (what the Givens step reads besides the norm is requested first: one round trip beside the reduction's)
+    const GivensPre pre = givens_prefetch(gr.ka, gr.loc, gr.h);
     if (gr.fin_n > 0) {
         double *red = lds;
+        double *slot = gr.fin_partials + (size_t)gr.fin_n * kPartialLd;  // the multiplier entries' share
+        double lam2 = 0.0;
+        if (threadIdx.x == 0) lam2 = peek(slot);
         final_reduce<2>(gr.fin_partials, gr.fin_n, kPartialLd, 1, red, gr.fe);
         if (threadIdx.x == 0) {
-            double *slot = gr.fin_partials + (size_t)gr.fin_n * kPartialLd;  // the multiplier entries' share
-            const double lam2 = peek(slot);
             publish(slot, __longlong_as_double((long long)kSentinelBits));   // re-armed for the next user of the row
             red[0] = red[0] + lam2;
         }
@@ -424,7 +456,7 @@ __device__ __forceinline__ void givens_rider(const GivensRider &gr, double *lds)
     // un-normalised basis: the scale factor of the vector the MAXPY launch just wrote (its norm is all-reduced by now)
     // (nothing compounds: V~_j = w' of the product of the NORMALISED v_{j-1}, so ||V~_j|| = h_{j,j-1} <= ||K M^-1||)
     if (gr.sc && threadIdx.x == 0) gr.sc[gr.loc + 1] = inv_norm(*gr.nrm2);
-    givens_block_lds<true>(gr.ka, gr.loc, gr.h, gr.nrm2, nullptr, lds + kThreads, kMaxNv + 2);
+    givens_block_lds<true>(gr.ka, gr.loc, gr.h, gr.nrm2, nullptr, lds + kThreads, kMaxNv + 2, &pre);
 }
 
 void givens_rider_alone(const GivensRider &gr, const int32_t *done, hipStream_t s);  // spk_k_krylov.hip
