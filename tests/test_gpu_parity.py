@@ -738,6 +738,24 @@ def test_row_partitioned_solver_matches_single_rank(spk, oracle, P, single):
     assert relerr(x, xo) < 1e-8
 
 
+def test_row_partitioned_long_restart(spk, oracle):
+    """Restart 100 (the step-by-step path with chunked Gram-Schmidt) across two ranks: the all-reduce then carries up
+    to 101 inner products at once, and every rank must still take the same branches."""
+    mx, my = 24, 26
+    A, f = spk.AssembleOperator_Laplace(mx, my)
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    rhs = np.concatenate([f, g])
+    n = A.nrows
+    out = _run_ranks(spk, 2, mx, my, spk.PC_SCHUR, spk.SCHUR_FULL, rhs, True, rtol=1e-10, restart=100)
+    xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=1e-10, restart=100)
+    x = np.zeros(n + 4)
+    for (b, e, yr, zr, xr, info, sz) in out:
+        x[b:e], x[n:] = xr[:-4], xr[-4:]
+        assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 1
+        assert np.array_equal(info["history"], out[0][5]["history"])
+    assert relerr(x, xo) < 1e-8
+
+
 def _launch_peer_worker(tmp_path, P, mode, port, env_extra=None, timeout=280):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
