@@ -62,6 +62,46 @@ def test_spmv_irregular_rows(spk, oracle):
     assert np.allclose(y[~short], y_ref[~short], rtol=1e-12, atol=1e-12)  # long rows: tree order
 
 
+@pytest.mark.parametrize("bs,fmt,long_len", [(2, "bcsr2x2", 700), (3, "bcsr3x3", 300)])
+def test_spmv_blocked_irregular(spk, oracle, bs, fmt, long_len):
+    """The blocked copies on ragged block structure: block rows of 1..40 blocks in arbitrary column order, one block
+    row longer than a tile (strided path: tree order), tiles cut at odd places -- SpMV bitwise equal to the oracle's
+    CSR loop on every row a tile holds; the FP32 sweeps (3 x 3: from the single-precision planes, the long block row by
+    its own CSR-order path) bit for bit."""
+    rng = np.random.default_rng(11 + bs)
+    nb = 900
+    lens = rng.integers(1, 41, nb)
+    lens[37] = long_len
+    lens[899] = 1
+    rp, ci, va = [0], [], []
+    for br in range(nb):
+        cols = rng.choice(nb, size=lens[br], replace=False)
+        if br not in cols:
+            cols[0] = br                       # a diagonal block in every block row (Jacobi needs the diagonal)
+        blocks = rng.standard_normal((lens[br], bs, bs))
+        for j, c in enumerate(cols):
+            if c == br:
+                blocks[j] += 50.0 * np.eye(bs)
+        for r in range(bs):
+            for j, c in enumerate(cols):
+                ci.extend(range(bs * c, bs * c + bs))
+                va.extend(blocks[j, r])
+            rp.append(len(ci))
+    A = spk.CSR(np.array(rp, np.int32), np.array(ci, np.int32), np.array(va), bs * nb)
+    x = _x(bs * nb, 5)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        assert c.spmv_info()["format"] == fmt
+        y = c.mult(x)
+        c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.7)
+        z = c.pc_apply(x)
+    y_ref = oracle.spmv(A, x)
+    short = np.repeat(lens <= (512 if bs == 2 else 256), bs)
+    assert np.array_equal(y[short], y_ref[short])
+    assert np.allclose(y[~short], y_ref[~short], rtol=1e-12, atol=1e-12) and (~short).sum() == bs
+    assert np.array_equal(z, oracle.pc_apply_inner(A, None, oracle.PC_JACOBI, 0, 3, 0.7, x))
+
+
 def test_spmv_full_size_1024(spk, oracle):
     """BASELINE config grid 1024 x 1024 (2.1 M rows, 37.7 M stored non-zeros)."""
     A, _ = spk.AssembleOperator_Laplace(1024)
