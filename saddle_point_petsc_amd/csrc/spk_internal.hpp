@@ -105,6 +105,7 @@ struct BcsrDev {
     int64_t nblocks = 0;
     DevBuf<int32_t> browptr, bcol;
     DevBuf<double> vtop, vbot;  // (a00,a01) and (a10,a11) per block
+    DevBuf<float> vtop32, vbot32;  // the same in single precision, for the FP32 inner sweeps (spk_pc_setup with sweeps)
     DevBuf<int32_t> tile_brow;
     DevBuf<int32_t> tile_desc;  // per tile {first block row, end block row, first block, end block} (one load instead of a chain)
     int32_t ntiles = 0;
@@ -364,6 +365,8 @@ void spmv_bcsr3(const Bcsr3Dev &A, const double *x, double *y, const CsrDev *bt,
 void build_b3tiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
 void bcsr3_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, int32_t *browptr, int32_t *bcol, double *v,
                 int64_t ldp, int32_t *fail, hipStream_t s);
+void jacobi_sweep_f32_b2(const BcsrDev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                         const int32_t *done, hipStream_t s);
 void jacobi_sweep_f32_b3(const Bcsr3Dev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
                          const int32_t *done, hipStream_t s);
 // KSPSetOperators on the device: count off-rank entries per row, exclusive scan, split, 2x2 blocking

@@ -777,6 +777,77 @@ void jacobi_sweep_f32(const CsrDev &A, const float *val32, const float *d32, flo
                        A.tile_row.p, A.ntiles, tpx, d32, omega, x32, yin, yout, done);
 }
 
+// The same sweep from the 2x2-blocked copy with single-precision value planes (5 B per stored non-zero against 8):
+// products rounded once each, summed per row in block order = CSR order -- the same bits as the CSR sweep and the oracle.
+__global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_b2_kernel(
+    const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol, const float *__restrict__ vtop32,
+    const float *__restrict__ vbot32, const int32_t *__restrict__ tile_brow, int ntiles, int tiles_per_xcd,
+    const float *__restrict__ d32, float omega, const float *__restrict__ x32, const float *__restrict__ yin,
+    float *__restrict__ yout, const int32_t *__restrict__ done)
+{
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own (the oracle's float loop)
+    if (done && *done) return;
+    const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    __shared__ float prod[kBTile * 4];
+    const int br0 = tile_brow[t], br1 = tile_brow[t + 1];
+    const int b0 = browptr[br0], b1 = browptr[br1];
+    const int cnt = b1 - b0;
+    if (cnt > kBTile) {  // one block row longer than a tile: its two rows by two threads, CSR order
+        if (threadIdx.x < 2) {
+            const int rr = threadIdx.x, r = 2 * br0 + rr;
+            const float *vv = rr ? vbot32 : vtop32;
+            float s = 0.0f;
+            for (int q = b0; q < b1; ++q) {
+                const int c = bcol[q];
+                s = (s + (vv[2 * (int64_t)q] * yin[2 * (int64_t)c]));
+                s = (s + (vv[2 * (int64_t)q + 1] * yin[2 * (int64_t)c + 1]));
+            }
+            yout[r] = yin[r] + ((omega * d32[r]) * (x32[r] - s));
+        }
+        return;
+    }
+    constexpr int kSteps = kBTile / kThreads;
+#pragma unroll
+    for (int i = 0; i < kSteps; ++i) {
+        const int q = i * kThreads + threadIdx.x;
+        if (q < cnt) {
+            const int c = __builtin_nontemporal_load(bcol + b0 + q);
+            const float2 tp = reinterpret_cast<const float2 *>(vtop32)[b0 + q];
+            const float2 bo = reinterpret_cast<const float2 *>(vbot32)[b0 + q];
+            const float2 yv = reinterpret_cast<const float2 *>(yin)[c];
+            float4 p;
+            p.x = (tp.x * yv.x);
+            p.y = (tp.y * yv.y);
+            p.z = (bo.x * yv.x);
+            p.w = (bo.y * yv.y);
+            *reinterpret_cast<float4 *>(prod + 4 * q) = p;
+        }
+    }
+    __syncthreads();
+    const int lr = threadIdx.x;
+    if (lr < 2 * (br1 - br0)) {
+        const int br = br0 + (lr >> 1), half = lr & 1;
+        const int k0 = browptr[br] - b0, k1 = browptr[br + 1] - b0;
+        float s = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+            const float2 p = *reinterpret_cast<const float2 *>(prod + 4 * k + 2 * half);
+            s = (s + p.x);
+            s = (s + p.y);
+        }
+        const int r = 2 * br0 + lr;
+        yout[r] = yin[r] + ((omega * d32[r]) * (x32[r] - s));
+    }
+}
+void jacobi_sweep_f32_b2(const BcsrDev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                         const int32_t *done, hipStream_t s)
+{
+    if (A.nbrows == 0) return;
+    const int tpx = (A.ntiles + 7) / 8;
+    hipLaunchKernelGGL(jacobi_sweep_f32_b2_kernel, dim3(tpx * 8), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, A.vtop32.p,
+                       A.vbot32.p, A.tile_brow.p, A.ntiles, tpx, d32, omega, x32, yin, yout, done);
+}
+
 // The same sweep from the 3x3-blocked copy with single-precision planes (4.44 B per stored non-zero against 8):
 // products rounded once each, summed per row in block order = CSR order -- the same bits as the CSR sweep and the oracle.
 __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_b3_kernel(

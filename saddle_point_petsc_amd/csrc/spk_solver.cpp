@@ -795,11 +795,19 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     // FP32 copies for the inner solve
     c->a32.release(); c->d32.release(); c->x32.release(); c->y32a.release(); c->y32b.release();
     c->Ab3.v32.release();
+    c->Ab.vtop32.release();
+    c->Ab.vbot32.release();
+    if (c->inner_sweeps > 0 && c->spmv_format == 1) {   // ... or the 2x2-blocked value planes
+        c->Ab.vtop32.alloc_raw((size_t)(2 * c->Ab.nblocks + 8), 32);
+        c->Ab.vbot32.alloc_raw((size_t)(2 * c->Ab.nblocks + 8), 32);
+        k::cvt_vals_f32(c->Ab.vtop.p, c->Ab.vtop32.p, 2 * c->Ab.nblocks, s);
+        k::cvt_vals_f32(c->Ab.vbot.p, c->Ab.vbot32.p, 2 * c->Ab.nblocks, s);
+    }
     if (c->inner_sweeps > 0 && c->spmv_format == 2) {   // the sweeps read the 3x3-blocked planes in single precision
         c->Ab3.v32.alloc_raw((size_t)(9 * c->Ab3.ldp), 32);
         k::cvt_vals_f32(c->Ab3.v.p, c->Ab3.v32.p, 9 * c->Ab3.ldp, s);
     }
-    if (c->inner_sweeps > 0 && c->spmv_format != 2) {
+    if (c->inner_sweeps > 0 && c->spmv_format == 0) {
         c->a32.alloc((size_t)c->Ad.nnz, 32);
         k::cvt_vals_f32(c->Ad.val.p, c->a32.p, c->Ad.nnz, s);
     }
@@ -854,6 +862,7 @@ static void inner_apply(spk_ctx *c, const double *x, double *y, int mode, const 
             c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
         }
         if (c->spmv_format == 2) k::jacobi_sweep_f32_b3(c->Ab3, c->d32.p, om, c->x32.p, ya, yb, done, s);
+        else if (c->spmv_format == 1) k::jacobi_sweep_f32_b2(c->Ab, c->d32.p, om, c->x32.p, ya, yb, done, s);
         else k::jacobi_sweep_f32(c->Ad, c->a32.p, c->d32.p, om, c->x32.p, ya, yb, done, s);
         if (c->n_ghost > 0) k::sweep_offdiag_f32(c->Ao, c->ao_rows.p, c->d32.p, om, c->xghost.p, yb, done, s);
         std::swap(ya, yb);
