@@ -418,6 +418,7 @@ void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int6
 void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s);
 // y = a*x + b*y with host scalars (b = 0: y = a*x without reading y)
 void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s);
+void vec_sub(const double *x, const double *y, double *z, int64_t n, const int32_t *done, hipStream_t s);  // z = x - y
 // f.out[0] = x.x over the first n_dot entries
 void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s);
 // gather x[idx[i]] -> out[i]

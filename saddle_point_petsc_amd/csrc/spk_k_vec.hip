@@ -760,6 +760,25 @@ __global__ __launch_bounds__(kThreads) void axpby_kernel(double a, const double 
         reinterpret_cast<double2 *>(y)[i] = yv;
     }
 }
+// z = x - y (the restart's true residual b - K x in one pass instead of a copy and an update: the same bits)
+__global__ __launch_bounds__(kThreads) void vec_sub_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                           double *__restrict__ z, int64_t n2, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+        const double2 xv = reinterpret_cast<const double2 *>(x)[i], yv = reinterpret_cast<const double2 *>(y)[i];
+        double2 zv;
+        zv.x = xv.x - yv.x;
+        zv.y = xv.y - yv.y;
+        reinterpret_cast<double2 *>(z)[i] = zv;
+    }
+}
+void vec_sub(const double *x, const double *y, double *z, int64_t n, const int32_t *done, hipStream_t s)
+{
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 4);
+    hipLaunchKernelGGL(vec_sub_kernel, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, x, y, z, n2, done);
+}
 void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n + 1) / 2;

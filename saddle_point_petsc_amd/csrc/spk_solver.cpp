@@ -1399,8 +1399,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);
-        k::axpby(1.0, b, 0.0, Vj(0), N, done, s);
-        k::axpby(-1.0, c->tmp.p, 1.0, Vj(0), N, done, s);
+        k::vec_sub(b, c->tmp.p, Vj(0), N, done, s);
         ++cycles;
         SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
         SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
