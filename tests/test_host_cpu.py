@@ -315,3 +315,28 @@ def test_ksp_options_follow_the_petsc_names(spk):
     k.destroy()
     assert spk.lib.SpkKSPConvergedReasonName(2) == b"CONVERGED_RTOL"
     assert spk.lib.SpkKSPConvergedReasonName(-3) == b"DIVERGED_ITS"
+
+
+def test_bench_byte_model_counts_the_iterations_actually_timed():
+    """bench.py::solve_bytes: the algorithmic bytes of one solve, summed over the iterations and cycle ends that ran
+    (the model used to assume whole restart cycles whatever --steps was), for the iteration form that ran."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    n, nnz, nnzB, p, m = 1000, 18000, 2000, 2, 4
+    vec, mat = 8 * n, 12 * nnz
+    spmv = mat + 4 * (n + 1) + 2 * vec + vec
+    cyc_end = lambda L: (L + 2) * vec + (mat + 4 * (n + 1) + 2 * vec + 2 * 12 * nnzB + 4 * n + 5 * vec)
+    cyc_begin = (1 + m) * vec
+    # 3 iterations of one cycle, normalised (four-launch) form: head + SpMV + MDot + MAXPY per iteration
+    it = lambda j: (4 + 1 + p) * vec + spmv + (j + 2) * vec + (j + 3 + p) * vec
+    assert bench.solve_bytes(n, nnz, nnzB, 30, 3, p, m, None, False) == vec + cyc_begin + sum(it(j) for j in range(3)) + cyc_end(3)
+    # un-normalised form: the head is paid by iteration 0 of a cycle only; MDot carries the planes, MAXPY the PC's traffic
+    itu = lambda j: spmv + (j + 2 + p) * vec + (j + 5 + 1 + p) * vec + ((4 + 1 + p) * vec if j == 0 else 0)
+    assert bench.solve_bytes(n, nnz, nnzB, 30, 3, p, m, None, True) == vec + cyc_begin + sum(itu(j) for j in range(3)) + cyc_end(3)
+    # 35 steps at restart 30: one full cycle and 5 iterations of the next, two cycle ends
+    full = vec + 2 * cyc_begin + sum(itu(j) for j in range(30)) + sum(itu(j) for j in range(5)) + cyc_end(30) + cyc_end(5)
+    assert bench.solve_bytes(n, nnz, nnzB, 30, 35, p, m, None, True) == full
+    # per-iteration average grows with the basis: 20 steps of one cycle move fewer bytes per step than 30
+    assert bench.solve_bytes(n, nnz, nnzB, 30, 20, p, m) / 20 < bench.solve_bytes(n, nnz, nnzB, 30, 30, p, m) / 30
