@@ -412,15 +412,19 @@ void build_bd(const CsrDev &Bt, const double *dinv, int m, int64_t ldb, double *
 // rows 2q, 2q+1 of B D interleaved by parity into one plane each (bd_packed = 1 in the kernels that
 // stream them); *bad != 0: the rows do not have that structure
 void pack_bd(const double *bd, int64_t ldb, int64_t n, int m, double *bdp, int32_t *bad, hipStream_t s);
-void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
-               double *w1side, const Finish &f, const int32_t *done, hipStream_t s);
+// (sa != nullptr: x = sa - sb is formed and stored in the same pass)
+void sqnorm_bd(double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
+               double *w1side, const Finish &f, const int32_t *done, hipStream_t s, const double *sa = nullptr,
+               const double *sb = nullptr);
 // x *= *alpha_dev
 void scale_dev(double *x, int64_t n, const double *alpha_dev, const int32_t *done, hipStream_t s);
 // y = a*x + b*y with host scalars (b = 0: y = a*x without reading y)
 void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s);
-void vec_sub(const double *x, const double *y, double *z, int64_t n, const int32_t *done, hipStream_t s);  // z = x - y
 // f.out[0] = x.x over the first n_dot entries
 void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done, hipStream_t s);
+// x[0..n) = sa - sb and f.out[0] = x.x over the first n_dot entries, one pass
+void sqnorm_sub(const double *sa, const double *sb, double *x, int64_t n, int64_t n_dot, const Finish &f, const int32_t *done,
+                hipStream_t s);
 // gather x[idx[i]] -> out[i]
 void gather(const double *x, const int32_t *idx, int64_t n, double *out, const int32_t *done, hipStream_t s);
 // peer-store collectives (stand-alone launches; the fused forms live in the reducing kernels)

@@ -760,25 +760,6 @@ __global__ __launch_bounds__(kThreads) void axpby_kernel(double a, const double 
         reinterpret_cast<double2 *>(y)[i] = yv;
     }
 }
-// z = x - y (the restart's true residual b - K x in one pass instead of a copy and an update: the same bits)
-__global__ __launch_bounds__(kThreads) void vec_sub_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                                           double *__restrict__ z, int64_t n2, const int32_t *__restrict__ done)
-{
-    if (done && *done) return;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
-        const double2 xv = reinterpret_cast<const double2 *>(x)[i], yv = reinterpret_cast<const double2 *>(y)[i];
-        double2 zv;
-        zv.x = xv.x - yv.x;
-        zv.y = xv.y - yv.y;
-        reinterpret_cast<double2 *>(z)[i] = zv;
-    }
-}
-void vec_sub(const double *x, const double *y, double *z, int64_t n, const int32_t *done, hipStream_t s)
-{
-    const int64_t n2 = (n + 1) / 2;
-    const int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 4);
-    hipLaunchKernelGGL(vec_sub_kernel, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, x, y, z, n2, done);
-}
 void axpby(double a, const double *x, double b, double *y, int64_t n, const int32_t *done, hipStream_t s)
 {
     const int64_t n2 = (n + 1) / 2;
@@ -786,16 +767,26 @@ void axpby(double a, const double *x, double b, double *y, int64_t n, const int3
     hipLaunchKernelGGL(axpby_kernel, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, a, x, b, y, n2, done);
 }
 
-__global__ __launch_bounds__(kVT) void sqnorm_kernel(const double *__restrict__ x, int64_t n2,
+__global__ __launch_bounds__(kVT) void sqnorm_kernel(double *__restrict__ x, int64_t n2,
                                                           int64_t n_dot, double *__restrict__ partials,
                                                           double *__restrict__ out, FinErr fe,
-                                                          const int32_t *__restrict__ done)
+                                                          const int32_t *__restrict__ done,
+                                                          const double *__restrict__ sa, const double *__restrict__ sb)
 {
+    // sa != nullptr: x = sa - sb formed and stored on the way (see sqnorm_bd_kernel); n2 then covers the whole vector
     if (done && *done) return;
     __shared__ double red[kVT];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kVT + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVT) {
-        const double2 v = reinterpret_cast<const double2 *>(x)[i];
+        double2 v;
+        if (sa) {
+            const double2 av = reinterpret_cast<const double2 *>(sa)[i], bv = reinterpret_cast<const double2 *>(sb)[i];
+            v.x = av.x - bv.x;
+            v.y = av.y - bv.y;
+            reinterpret_cast<double2 *>(x)[i] = v;
+        } else {
+            v = reinterpret_cast<const double2 *>(x)[i];
+        }
         if (2 * i < n_dot) acc += v.x * v.x;
         if (2 * i + 1 < n_dot) acc += v.y * v.y;
     }
@@ -816,7 +807,17 @@ void sqnorm(const double *x, int64_t n_dot, const Finish &f, const int32_t *done
 {
     const int64_t n2 = (n_dot + 1) / 2;
     const int grid = vec_grid(n2);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, const_cast<double *>(x), n2, n_dot, f.partials, f.out,
+                       FinErr{f.err, f.fin_ticks}, done, (const double *)nullptr, (const double *)nullptr);
+}
+// x[0..n) = sa - sb and ||x[0..n_dot)||^2 in one pass (the restart's true residual and the next cycle's starting norm)
+void sqnorm_sub(const double *sa, const double *sb, double *x, int64_t n, int64_t n_dot, const Finish &f, const int32_t *done,
+                hipStream_t s)
+{
+    const int64_t n2 = (n + 1) / 2;
+    const int grid = vec_grid(n2);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(grid), dim3(kVT), 0, s, x, n2, n_dot, f.partials, f.out, FinErr{f.err, f.fin_ticks},
+                       done, sa, sb);
 }
 
 __global__ __launch_bounds__(kThreads) void gather_kernel(const double *__restrict__ x,
@@ -1001,12 +1002,15 @@ void pack_bd(const double *bd, int64_t ldb, int64_t n, int m, double *bdp, int32
 
 // out[0] = r.r (first n_dot entries), out[1+q] = sum_i (B D)[i][q] r_i : cycle start of the fused path
 template <int MP>
-__global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict__ x, int64_t n2, int64_t n_dot,
+__global__ __launch_bounds__(512) void sqnorm_bd_kernel(double *__restrict__ x, int64_t n2, int64_t n_dot,
                                                         const double *__restrict__ bd, int64_t ldb, int64_t n_bd,
                                                         int m, double *__restrict__ w1side,
                                                         double *__restrict__ partials, double *__restrict__ out,
-                                                        FinErr fe, const int32_t *__restrict__ done)
+                                                        FinErr fe, const int32_t *__restrict__ done,
+                                                        const double *__restrict__ sa, const double *__restrict__ sb)
 {
+    // sa != nullptr: x = sa - sb is formed (and stored) on the way -- the restart's true residual b - K x and the
+    // norms the next cycle starts from in ONE pass
     if (done && *done) return;
     constexpr int T = 512, NR = MP + 1, W = T / kWave;
     __shared__ double red[(W * NR > T) ? W * NR : T];
@@ -1014,7 +1018,15 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < n2; i += (int64_t)gridDim.x * T) {
-        const double2 v = reinterpret_cast<const double2 *>(x)[i];
+        double2 v;
+        if (sa) {
+            const double2 av = reinterpret_cast<const double2 *>(sa)[i], bv = reinterpret_cast<const double2 *>(sb)[i];
+            v.x = av.x - bv.x;
+            v.y = av.y - bv.y;
+            reinterpret_cast<double2 *>(x)[i] = v;
+        } else {
+            v = reinterpret_cast<const double2 *>(x)[i];
+        }
         if (2 * i < n_dot) acc[0] += v.x * v.x;
         if (2 * i + 1 < n_dot) acc[0] += v.y * v.y;
         {
@@ -1048,15 +1060,15 @@ __global__ __launch_bounds__(512) void sqnorm_bd_kernel(const double *__restrict
     final_reduce(partials, gridDim.x, kPartialLd, 1 + m, red, fe);
     if ((int)threadIdx.x < 1 + m) out[threadIdx.x] = red[threadIdx.x];
 }
-void sqnorm_bd(const double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
-               double *w1side, const Finish &f, const int32_t *done, hipStream_t s)
+void sqnorm_bd(double *x, int64_t n, int64_t n_dot, const double *bd, int64_t ldb, int64_t n_bd, int m,
+               double *w1side, const Finish &f, const int32_t *done, hipStream_t s, const double *sa, const double *sb)
 {
     const int64_t n2 = (n + 1) / 2;
     const int grid = vec_grid(n2, 512);
     if (m <= 4)
-        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<4>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done, sa, sb);
     else
-        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done);
+        hipLaunchKernelGGL(sqnorm_bd_kernel<8>, dim3(grid), dim3(512), 0, s, x, n2, n_dot, bd, ldb, n_bd, m, w1side, f.partials, f.out, FinErr{f.err, f.fin_ticks}, done, sa, sb);
 }
 
 __global__ void sum_slots_kernel(const double *__restrict__ slots, int nslots, int ld, int count,

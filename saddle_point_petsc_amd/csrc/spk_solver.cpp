@@ -1080,8 +1080,11 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     int cycles = 0;
     for (;;) {
         // ---- cycle start: ||r|| (parity slot 1 = "iteration -1"), convergence test, v0 = r/||r|| ----
-        if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
-        else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
+        // (from the second cycle on the previous cycle's end has formed r = b - K x and these sums in one pass)
+        if (cycles == 0) {
+            if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s);
+            else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
+        }
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
         k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two || ba || un3) ? c->ka.tb : nullptr, m,
                               (ba || un3) ? c->ba_sc.p : nullptr);
@@ -1399,7 +1402,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);
-        k::vec_sub(b, c->tmp.p, Vj(0), N, done, s);
+        // r = b - K x into V0 together with ||r||^2 (and B D r) for the start of the next cycle
+        if (fused) k::sqnorm_bd(Vj(0), N, n_dot, c->bd.p, ld, nl, m, w1side, c->fin(nrmbuf(1)), done, s, b, c->tmp.p);
+        else k::sqnorm_sub(b, c->tmp.p, Vj(0), N, n_dot, c->fin(nrmbuf(1)), done, s);
         ++cycles;
         SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
         SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
