@@ -6,8 +6,10 @@ namespace spk {
 namespace k {
 
 // ---------------------------------------------------------------------------
-// Two-launch iteration (opts.iteration_form; the default below ~1 M rows, i.e. for a rank's slab of a
-// strong-scaling run and the 256^2 / 512^2 grids).  On such vectors every kernel of the four-launch
+// Two- / three-launch iteration on a NORMALISED basis (opts.iteration_form = 2 / 3: opt-in since the un-normalised
+// form -- kernel B in `sc` mode behind a plain MDot, the plain SpMV carrying the Givens step -- became the default;
+// kept for comparison and as the origin of kernel B).  On a rank's slab of a strong-scaling run and the
+// 256^2 / 512^2 grids every kernel of the four-launch
 // iteration costs ~5 us beyond its bytes (launch boundary, first-load latency, publish -> re-read of
 // the reduction): 45-50 us against a 27 us byte floor on the 1/8 slab of the 1024^2 grid.  Same
 // algorithm -- classical Gram-Schmidt with the norm taken directly from w', two reductions -- in TWO
