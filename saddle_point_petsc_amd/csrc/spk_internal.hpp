@@ -626,7 +626,9 @@ void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double
                 const KrylovArrays &ka, int loc, const int32_t *done, hipStream_t s, const SendRanges *sr = nullptr,
                 int bd_packed = 0);
 // sc: y_i *= sc[i] (un-normalised Z); restart > kMaxNv - 2: the triangle stays in global memory
-void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc = nullptr, int restart = 0);
+// pending: the Givens step of the cycle's last iteration, run first in the same launch (ka, loc, h, nrm2 are read)
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc = nullptr, int restart = 0,
+                      const GivensRider *pending = nullptr);
 // CGS refinement: decide (device side) whether the second pass runs, then fold its results
 // (h2 into h, norm/traw of the refined vector over the first pass's)
 void krylov_refine_decide(const KrylovArrays &ka, int loc, int mode, const double *dots, const double *nrm2,

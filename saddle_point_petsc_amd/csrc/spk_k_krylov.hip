@@ -549,35 +549,71 @@ void krylov_refine_merge(const KrylovArrays &ka, int loc, double *dots, const do
     hipLaunchKernelGGL(krylov_refine_merge_kernel, dim3(1), dim3(64), 0, s, ka, loc, dots, dots2, nrm, nrm_b, nn);
 }
 
-// back substitution for the loc_done columns built in this cycle; the triangle is staged
-// in LDS by the whole workgroup first (450 dependent global loads took 47 us)
-__global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka, const double *sc)
+// Back substitution for the loc_done columns built in this cycle (KSPFGMRESBuildSoln).  The triangle is staged in LDS by
+// the whole workgroup (450 dependent global loads took 47 us); then ONE WAVE solves it: lane j keeps y_j in a register,
+// the products H_kj y_j of a row are formed by all lanes at once (one LDS round trip per row) and subtracted from rs_k in
+// ascending j through v_readlane -- the order and the roundings of the serial loop `t -= H(k,j) * y[j]` without FMA
+// contraction, i.e. of the oracle's C loop.  (One lane walking the triangle out of LDS paid a round trip per entry:
+// 19.8 us per cycle end at restart 30, 43-52 us at 60.)
+// pend.loc >= 0: the Givens step of the cycle's last iteration runs first, in the same launch.
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka, const double *sc, GivensRider pend)
 {
     __shared__ double Hs[(kMaxNv) * (kMaxNv + 1)];
-    __shared__ double rss[kMaxNv + 2], ys[kMaxNv + 2];
+    __shared__ double rss[kMaxNv + 2];
+    if (pend.loc >= 0) {
+        givens_block(pend.ka, pend.loc, pend.h, pend.nrm2);
+        __syncthreads();
+    }
     KrylovState *st = ka.st;
     const int n = st->loc_done, ldh = ka.ldh;
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-        const int k = e % n, j = e / n;  // row k, column j
-        Hs[j * n + k] = ka.H[(size_t)ldh * j + k];
+    {
+        // four threads per column, every load of a thread requested before its first LDS store (the strided loop with
+        // a division per entry made four dependent round trips of it: ~10 us of this kernel's 20)
+        const int j = threadIdx.x >> 2, k0 = threadIdx.x & 3;
+        constexpr int kPer = (kMaxNv + 3) / 4;
+        double hv[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int k = k0 + 4 * u;
+            hv[u] = (j < n && k <= j) ? ka.H[(size_t)ldh * j + k] : 0.0;   // upper triangle only
+        }
+        const double rv = (int)threadIdx.x < n ? ka.rs[threadIdx.x] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int k = k0 + 4 * u;
+            if (j < n && k <= j) Hs[j * n + k] = hv[u];
+        }
+        if ((int)threadIdx.x < n) rss[threadIdx.x] = rv;
     }
-    for (int k = threadIdx.x; k < n; k += blockDim.x) rss[k] = ka.rs[k];
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= kWave) return;
+    const int lane = threadIdx.x;  // n <= kMaxNv - 2 < 64: lane j owns y_j
+    const double scl = (sc && lane < n) ? sc[lane] : 1.0;
+    double y = 0.0;
     for (int k = n - 1; k >= 0; --k) {
+        const double p = (lane > k && lane < n) ? Hs[lane * n + k] * y : 0.0;
         double t = rss[k];
-        for (int j = k + 1; j < n; ++j) t -= Hs[j * n + k] * ys[j];
+        for (int j = k + 1; j < n; ++j) t -= readlane_f64(p, j);
         const double piv = Hs[k * n + k];
-        if (piv == 0.0) {
-            if (st->reason >= 0) st->reason = SPK_DIVERGED_BREAKDOWN;
-            st->done = 1;
-            st->loc_done = 0;
+        if (piv == 0.0) {  // (uniform)
+            if (lane == 0) {
+                if (st->reason >= 0) st->reason = SPK_DIVERGED_BREAKDOWN;
+                st->done = 1;
+                st->loc_done = 0;
+            }
             return;
         }
-        ys[k] = t / piv;
+        const double yk = t / piv;
+        if (lane == k) y = yk;
     }
-    // (un-normalised Z~_k of the BA iteration: x += sum y_k sc_k Z~_k)
-    for (int k = 0; k < n; ++k) ka.nrs[k] = sc ? ys[k] * sc[k] : ys[k];
+    // (un-normalised Z~_k: x += sum y_k sc_k Z~_k)
+    if (lane < n) ka.nrs[lane] = sc ? y * scl : y;
 }
 // The same back substitution for restart lengths whose triangle does not fit LDS (-ksp_gmres_restart > 62): one thread,
 // same order of operations, H read from global memory eight entries at a time (the loads do not depend on the chain)
@@ -609,10 +645,14 @@ __global__ __launch_bounds__(64) void krylov_cycle_end_big_kernel(KrylovArrays k
     }
     for (int k = 0; k < n; ++k) ka.nrs[k] = ys[k];
 }
-void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc, int restart)
+void krylov_cycle_end(const KrylovArrays &ka, hipStream_t s, const double *sc, int restart, const GivensRider *pending)
 {
-    if (restart > kMaxNv - 2) hipLaunchKernelGGL(krylov_cycle_end_big_kernel, dim3(1), dim3(64), 0, s, ka);
-    else hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka, sc);
+    if (restart > kMaxNv - 2) {
+        if (pending) krylov_givens(pending->ka, pending->loc, pending->h, pending->nrm2, s);
+        hipLaunchKernelGGL(krylov_cycle_end_big_kernel, dim3(1), dim3(64), 0, s, ka);
+    } else {
+        hipLaunchKernelGGL(krylov_cycle_end_kernel, dim3(1), dim3(256), 0, s, ka, sc, pending ? *pending : no_rider());
+    }
 }
 
 

@@ -1092,6 +1092,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
 
         bool stop = false;
         int last = -1;  // last iteration of this cycle whose Givens step is still pending (fused path)
+        int pend_loc = -1;   // ... handed to the cycle-end launch (its Hessenberg column and norm)
+        const double *pend_h = nullptr;
+        double *pend_n = nullptr;
         // single-reduction mode: the MAXPY of iteration loc also runs the head of iteration loc+1 and the
         // Givens step of iteration loc (k::maxpy_head): three launches and one reduction per iteration
         bool head_done = false, prev_inhead = false;
@@ -1163,7 +1166,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::GivensRider gr{c->ka, loc, sm2, nb, c->ba_sc.p, defer ? c->partials.p : nullptr, defer ? fin_n : 0,
                                       k::FinErr{c->errw.p, c->fin_ticks}, defer ? ar2 : k::PeerAR{}};
                     if (loc + 1 < mk) product(Zj(loc + 1), Vj(loc + 2), inb, &gr);
-                    else k::krylov_givens(c->ka, loc, sm2, nb, s);
+                    else pend_h = sm2, pend_n = nb, pend_loc = loc;   // no product behind it: the step runs in the cycle-end launch
                     last = -1;
                 }
                 if (ba) {
@@ -1396,9 +1399,12 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             }
         }
         // fused path: the Givens step of the cycle's last iteration has no head kernel to ride on
-        if (head && last >= 0) k::krylov_givens(c->ka, last, dotsbuf(last), nrmbuf(last), s);
+        if (head && last >= 0) pend_h = dotsbuf(last), pend_n = nrmbuf(last), pend_loc = last;
         // ---- x += Z y (KSPFGMRESBuildSoln); always runs, count comes from the device ----
-        k::krylov_cycle_end(c->ka, s, (ba || un3) ? c->ba_sc.p : nullptr, mk);
+        {
+            k::GivensRider pend{c->ka, pend_loc, pend_h, pend_n, nullptr, nullptr, 0, k::FinErr{nullptr, 0}, k::PeerAR{}};
+            k::krylov_cycle_end(c->ka, s, (ba || un3) ? c->ba_sc.p : nullptr, mk, pend_loc >= 0 ? &pend : nullptr);
+        }
         k::maxpy(Z, ld, mk, loc_done, c->ka.nrs, 1.0, x, N, 0, c->fin(nullptr), nullptr, s);
         // ---- true residual for the next cycle (KSPFGMRESResidual); skipped once done ----
         op_mult(c, x, c->tmp.p, done);
