@@ -100,6 +100,8 @@ int spk_destroy(spk_ctx *c)
     hipStream_t s = c->stream;
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (i == 0 && c->pin_state) (void)hipHostFree(c->pin_state);
+        if (i == 0 && c->state_ev) (void)hipEventDestroy(c->state_ev);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
     }
     delete c;  // DevBuf destructors free device memory

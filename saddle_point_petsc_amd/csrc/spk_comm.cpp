@@ -372,6 +372,7 @@ public:
     Comm *release_inner() { return inner_.release(); }
     const char *name() const override { return "peer-store"; }
     bool fuses() const override { return fuse_; }
+    const int32_t *error_dev() const override { return err_.p; }
     int rank() const override { return me_; }
     int size() const override { return P_; }
 

@@ -221,6 +221,9 @@ public:
     virtual const char *name() const { return "self"; }
     // true when the Krylov all-reduces ride in the finish of the reducing kernels (fused_allreduce returns windows)
     virtual bool fuses() const { return false; }
+    // device address of the backend's sticky error word (nullptr: none): the solver reads it with its own per-cycle
+    // state copy and calls check() only when it is set
+    virtual const int32_t *error_dev() const { return nullptr; }
     // in-place sum over ranks of `count` doubles in device memory, stream-ordered
     virtual void allreduce_sum(double *dev, int count, hipStream_t s) { (void)dev; (void)count; (void)s; }
     // exchange of packed halo segments: sendbuf[send_off[p]..] -> peer p,
@@ -726,6 +729,8 @@ struct spk_ctx {
     void ensure_vectors();
     // pageable host memory -> device through two pinned staging buffers (KSPSetOperators)
     void upload_staged(void *dst, const void *src, size_t bytes);
+    void *pin_state = nullptr;     // pinned landing place of the per-cycle state read-back (KrylovState + error words)
+    hipEvent_t state_ev = nullptr; // ... and the event behind its copies
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
