@@ -550,11 +550,13 @@ void krylov_refine_merge(const KrylovArrays &ka, int loc, double *dots, const do
 }
 
 // Back substitution for the loc_done columns built in this cycle (KSPFGMRESBuildSoln).  The triangle is staged in LDS by
-// the whole workgroup (450 dependent global loads took 47 us); then ONE WAVE solves it: lane j keeps y_j in a register,
-// the products H_kj y_j of a row are formed by all lanes at once (one LDS round trip per row) and subtracted from rs_k in
-// ascending j through v_readlane -- the order and the roundings of the serial loop `t -= H(k,j) * y[j]` without FMA
-// contraction, i.e. of the oracle's C loop.  (One lane walking the triangle out of LDS paid a round trip per entry:
-// 19.8 us per cycle end at restart 30, 43-52 us at 60.)
+// the whole workgroup (450 dependent global loads took 47 us); then ONE WAVE solves it column by column: lane k keeps
+// the running right-hand side t_k of row k in a register, y_j = t_j / H_jj is broadcast through v_readlane and every
+// row above takes its update t_k -= H_kj y_j at once.  The critical path is one division and one multiply-subtract per
+// unknown (measured: 20.7 us -> ~5 us at restart 30 against one lane walking the triangle row by row, which pays an LDS
+// round trip or a readlane per ENTRY).  Each row's sum runs over j in descending instead of ascending order: the same
+// terms, one rounding each, no tree -- deterministic and identical on every rank; it differs from the serial loop of
+// the oracle by rounding only.
 // pend.loc >= 0: the Givens step of the cycle's last iteration runs first, in the same launch.
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
@@ -593,14 +595,13 @@ __global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka, 
     }
     __syncthreads();
     if (threadIdx.x >= kWave) return;
-    const int lane = threadIdx.x;  // n <= kMaxNv - 2 < 64: lane j owns y_j
+    const int lane = threadIdx.x;  // n <= kMaxNv - 2 < 64: lane k owns row k
     const double scl = (sc && lane < n) ? sc[lane] : 1.0;
-    double y = 0.0;
-    for (int k = n - 1; k >= 0; --k) {
-        const double p = (lane > k && lane < n) ? Hs[lane * n + k] * y : 0.0;
-        double t = rss[k];
-        for (int j = k + 1; j < n; ++j) t -= readlane_f64(p, j);
-        const double piv = Hs[k * n + k];
+    double t = lane < n ? rss[lane] : 0.0, y = 0.0;
+    double hcol = (n > 0 && lane < n - 1) ? Hs[(n - 1) * n + lane] : 0.0;   // column n-1 above the diagonal
+    for (int j = n - 1; j >= 0; --j) {
+        const double piv = Hs[j * n + j];
+        const double hnext = (j > 0 && lane < j - 1) ? Hs[(j - 1) * n + lane] : 0.0;   // next column, requested early
         if (piv == 0.0) {  // (uniform)
             if (lane == 0) {
                 if (st->reason >= 0) st->reason = SPK_DIVERGED_BREAKDOWN;
@@ -609,8 +610,10 @@ __global__ __launch_bounds__(256) void krylov_cycle_end_kernel(KrylovArrays ka, 
             }
             return;
         }
-        const double yk = t / piv;
-        if (lane == k) y = yk;
+        const double yj = readlane_f64(t, j) / piv;
+        if (lane == j) y = yj;
+        if (lane < j) t -= hcol * yj;
+        hcol = hnext;
     }
     // (un-normalised Z~_k: x += sum y_k sc_k Z~_k)
     if (lane < n) ka.nrs[lane] = sc ? y * scl : y;
