@@ -460,6 +460,12 @@ void schur_y1(int fact, int m, const double *x1, const double *t, const double *
 void copy_small(const double *src, double *dst, int n, const int32_t *done, hipStream_t s);
 
 // Krylov scalar kernels (single wave)
+// where krylov_cycle_begin reports the solve's state to the host (pinned, device-visible memory)
+struct StateReport {
+    KrylovState *host_state;
+    int32_t *host_words;            // [0] reduction error word, [1] communicator error word
+    const int32_t *errw, *commerr;  // device words (nullptr: none)
+};
 struct KrylovArrays {
     KrylovState *st;
     double *H, *cc, *ss, *rs, *nrs, *hcol, *hist, *tb;
@@ -613,7 +619,7 @@ int iter_maxpy_uhead(IterB b, hipStream_t s);   // returns the number of partial
 int iter_slots(int tiles_per_xcd, int wg_per_cu);
 void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2, hipStream_t s);
 void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb = nullptr, int m = 0,
-                        double *sc = nullptr);
+                        double *sc = nullptr, const StateReport *report = nullptr);
 void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const double *nrm2, hipStream_t s);
 // head of a fused Schur iteration: VecScale + PCApply + B^T part of MatMult in one pass, plus the
 // previous iteration's Givens step in workgroup 0 (loc_prev < 0: none)

@@ -40,9 +40,8 @@ void krylov_init(const KrylovArrays &ka, const spk_opts &o, const double *bnorm2
     hipLaunchKernelGGL(krylov_init_kernel, dim3(1), dim3(64), 0, s, ka, o, bnorm2);
 }
 
-__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, double *tb, int m, double *sc)
+__device__ __forceinline__ void cycle_begin_body(const KrylovArrays &ka, const double *nrm2, double *tb, int m, double *sc)
 {
-    if (threadIdx.x != 0) return;
     KrylovState *st = ka.st;
     if (sc) sc[0] = 1.0;  // v_0 is normalised; later basis vectors carry their own scale (BA iteration)
     st->loc_done = 0;
@@ -78,9 +77,23 @@ __global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, d
     if (tb)  // B D v_0 for the single-reduction recurrence
         for (int r = 0; r < m; ++r) tb[r] = nrm2[1 + r] / rnorm;
 }
-void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb, int m, double *sc)
+// report: the verdict so far (the state as this cycle finds / leaves it, the reduction and communicator error words)
+// is written straight into pinned host memory -- the host reads it behind an event while the cycle is already running
+__global__ void krylov_cycle_begin_kernel(KrylovArrays ka, const double *nrm2, double *tb, int m, double *sc, StateReport rp)
 {
-    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, tb, m, sc);
+    if (threadIdx.x != 0) return;
+    cycle_begin_body(ka, nrm2, tb, m, sc);
+    if (rp.host_state) {
+        *rp.host_state = *ka.st;
+        rp.host_words[0] = rp.errw ? *rp.errw : 0;
+        rp.host_words[1] = rp.commerr ? *rp.commerr : 0;
+    }
+}
+void krylov_cycle_begin(const KrylovArrays &ka, const double *nrm2, hipStream_t s, double *tb, int m, double *sc,
+                        const StateReport *rp)
+{
+    hipLaunchKernelGGL(krylov_cycle_begin_kernel, dim3(1), dim3(64), 0, s, ka, nrm2, tb, m, sc,
+                       rp ? *rp : StateReport{nullptr, nullptr, nullptr, nullptr});
 }
 
 __global__ void krylov_givens_kernel(KrylovArrays ka, int loc, const double *dots, const double *nrm2)

@@ -1078,6 +1078,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     KrylovState st{};
     int32_t errword = 0;
     int cycles = 0;
+    // The solve's state reaches the host through pinned memory written by krylov_cycle_begin (no copy on the stream); the
+    // host waits for the event behind that launch only after it has enqueued the start of the cycle (kAhead iterations),
+    // whose kernels are gated off on the device if the solve is over: the stream never drains at a restart.  (Pageable
+    // read-back copies and a stream synchronisation per cycle cost 35-85 us of idle GPU: 256^2 28.1 -> 23.7 us per iteration.)
     if (!c->pin_state) SPK_HIP(hipHostMalloc(&c->pin_state, 512, hipHostMallocDefault));
     if (!c->state_ev) SPK_HIP(hipEventCreateWithFlags(&c->state_ev, hipEventDisableTiming));
     KrylovState *ps = (KrylovState *)c->pin_state;
@@ -1103,8 +1107,13 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
             else k::sqnorm(Vj(0), n_dot, c->fin(nrmbuf(1)), done, s);
         }
         c->comm->allreduce_sum(nrmbuf(1), nn, s);
+        // (the kernel also reports the state it finds / leaves into pinned memory: the verdict on the PREVIOUS cycle and,
+        // through its own convergence test on the true residual, on the solve -- read by the host at loc == kAhead)
+        const k::StateReport report{ps, pe, c->errw.p, c->comm->error_dev()};
         k::krylov_cycle_begin(c->ka, nrmbuf(1), s, (single || two || ba || un3) ? c->ka.tb : nullptr, m,
-                              (ba || un3) ? c->ba_sc.p : nullptr);
+                              (ba || un3) ? c->ba_sc.p : nullptr, &report);
+        SPK_HIP(hipEventRecord(c->state_ev, s));
+        pend_check = true;
         if (!head) k::scale_dev(Vj(0), N, inv_tt, done, s);
 
         bool stop = false;
@@ -1435,16 +1444,10 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         else k::sqnorm_sub(b, c->tmp.p, Vj(0), N, n_dot, c->fin(nrmbuf(1)), done, s);
         ++cycles;
         SPK_HIP(hipGetLastError());  // a rejected launch inside the cycle surfaces here, not as a wrong answer
-        // The cycle's verdict goes to pinned memory behind an event; the host looks at it only after it has enqueued the
-        // start of the NEXT cycle (read_state below), so the stream never drains at a restart.  (Pageable copies and a
-        // stream synchronisation here cost 35-85 us of idle GPU per cycle: 256^2 28.1 -> 24.5 us per iteration.)
-        SPK_HIP(hipMemcpyAsync(ps, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));
-        SPK_HIP(hipMemcpyAsync(pe, c->errw.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (c->comm->error_dev()) SPK_HIP(hipMemcpyAsync(pe + 1, c->comm->error_dev(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SPK_HIP(hipEventRecord(c->state_ev, s));
-        pend_check = true;
     }
     SPK_HIP(hipStreamSynchronize(s));  // (a speculative start of a cycle that will not run drains as no-ops)
+    c->comm->check(s);          // what was raised after the last report (once per solve: blocking reads)
+    c->check_device_error();
     const auto t1 = std::chrono::steady_clock::now();
 
     res->its = st.its;
