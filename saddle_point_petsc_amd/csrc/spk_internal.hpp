@@ -626,7 +626,7 @@ void krylov_givens(const KrylovArrays &ka, int loc, const double *dots, const do
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
                 const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
-                const SendRanges *sr = nullptr, int bd_packed = 0);
+                const SendRanges *sr = nullptr, int bd_packed = 0, double *wl_out = nullptr);
 // single-reduction mode: MAXPY of iteration loc + head of iteration loc+1 + Givens of iteration loc
 // in one pass (dots = reduced [h, B D w, w.w]; tb = B D v_i per basis vector, (restart+2) x 8)
 void maxpy_head(const double *V, int64_t ldv, int nv, const double *dots, double *tb, double *nrm_out, double *w,

@@ -137,9 +137,11 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
     const double *__restrict__ dinv, const double *__restrict__ bd, int64_t ldb,
     const double *__restrict__ shat, const double *__restrict__ gram, int fact, int64_t nl, int m,
     double *__restrict__ z, double *__restrict__ c, KrylovArrays ka, int loc_prev,
-    const double *__restrict__ dots_prev, SendRanges sr, int packed, const int32_t *__restrict__ done)
+    const double *__restrict__ dots_prev, SendRanges sr, int packed, const int32_t *__restrict__ done,
+    double *__restrict__ wl_out)
 {
     // packed: bd holds m/2 parity-interleaved planes (pack_bd_kernel) instead of m dense rows
+    // wl_out != nullptr: a side copy of the multiplier entries of c (the un-normalised iteration keeps them beside the basis)
     // c == nullptr: Jacobi head (K = A, m = 0): v = w'/||w'||, z = D v, nothing pre-loaded
     if (*done) return;
     __shared__ double ys[MP], xs[MP], ts[MP];
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
             v[nl + r] = xs[r];
             z[nl + r] = ys[r];
             c[nl + r] = w1;
+            if (wl_out) wl_out[r] = w1;
         }
         if (loc_prev >= 0) givens_block(ka, loc_prev, dots_prev, nrm);
         return;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void fused_head_kernel(
 void fused_head(double *v, const double *nrm, const double *w1raw, const double *dinv, const double *bd, int64_t ldb,
                 const double *shat, const double *gram, int fact, int64_t nl, int m, double *z, double *c,
                 const KrylovArrays &ka, int loc_prev, const double *dots_prev, const int32_t *done, hipStream_t s,
-                const SendRanges *srp, int packed)
+                const SendRanges *srp, int packed, double *wl_out)
 {
     const int64_t n2 = nl / 2;
     int grid = (int)std::min<int64_t>((n2 + kThreads - 1) / kThreads, kMaxBlocks * 2);
@@ -279,10 +282,10 @@ void fused_head(double *v, const double *nrm, const double *w1raw, const double 
     if (sr.peer) grid += (2 * sr.nrecv + kThreads - 1) / kThreads;  // the waiting workgroups come last
     if (m <= 4)
         hipLaunchKernelGGL(fused_head_kernel<4>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
-                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, packed, done);
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, packed, done, wl_out);
     else
         hipLaunchKernelGGL(fused_head_kernel<8>, dim3(grid > 0 ? grid : 1), dim3(kThreads), 0, s, v, nrm, w1raw, dinv, bd, ldb,
-                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, packed, done);
+                           shat, gram, fact, nl, m, z, c, ka, loc_prev, dots_prev, sr, packed, done, wl_out);
 }
 
 // ---------------------------------------------------------------------------

@@ -1154,12 +1154,11 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     const bool inhead = packed && c->comm->fused_halo(sr0, c->xghost.p);
                     if (fused)
                         k::fused_head(Vj(0), nrmbuf(1), w1side, c->dinv.p, bdp, ld, c->shat.p, c->gram.p, c->schur_fact, nl, m,
-                                      Zj(0), w, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr, bpk);
+                                      Zj(0), w, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr, bpk, wl(0));
                     else
                         k::fused_head(Vj(0), nrmbuf(1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER, nl, 0,
                                       Zj(0), nullptr, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr);
                     product(Zj(0), w, inhead);
-                    if (fused) k::copy_small(w + nl, wl(0), m, done, s);
                 }
                 // raw inner products of the un-normalised basis with w~ (and B D w~); scaled where they are consumed
                 {
