@@ -593,6 +593,9 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
     B.nnz = wrp.back();
     int32_t win = 8192;
     while ((int64_t)(nl + win - 1) / win > k::kMaxBlocks) win *= 2;
+    // small local sizes: narrower windows, so that the launch still has ~128 workgroups (a rank's 1/8 slab of the
+    // 1024^2 grid got 32 workgroups on 256 CUs: 12.6 us for 6 MB)
+    while (win > 1024 && (int64_t)(nl + win - 1) / win < 128) win /= 2;
     B.win = win;
     B.nwin = mw > 0 ? (nl + win - 1) / win : 0;
     std::vector<int32_t> winptr((size_t)(B.nwin + 1) * (size_t)std::max(mw, 1));
