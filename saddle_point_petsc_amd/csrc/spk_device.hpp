@@ -511,7 +511,9 @@ inline VecShape vec_shape(int64_t n2, bool maxpy = false)
 }
 inline int vec_grid(int64_t n2, int T = kVT)
 {
-    int64_t tiles = (n2 + (int64_t)T * kVecUnroll - 1) / ((int64_t)T * kVecUnroll);
+    // one double2 per thread and pass: small vectors still get a workgroup per CU (a 1/8 slab of the 1024^2 grid ran its
+    // restart norms on 64 workgroups)
+    int64_t tiles = (n2 + (int64_t)T - 1) / (int64_t)T;
     if (tiles < 1) tiles = 1;
     const int cap = T >= 512 ? kVecMaxBlocks : 2 * kVecMaxBlocks;
     return (int)(tiles < cap ? tiles : cap);
