@@ -45,6 +45,13 @@ __device__ __forceinline__ double2 ld2s(const double *p, int64_t i2)
     }
     return reinterpret_cast<const double2 *>(p)[i2];
 }
+__device__ __forceinline__ void st2nt(double *p, int64_t i2, double2 v)   // non-temporal 16-byte store
+{
+    dbl2v t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<dbl2v *>(p) + i2);
+}
 template <bool NT>
 __device__ __forceinline__ int4 ld4i(const int32_t *p)
 {
