@@ -1121,6 +1121,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
 
         bool stop = false;
         int last = -1;  // last iteration of this cycle whose Givens step is still pending (fused path)
+        int64_t its_cap = INT64_MAX;   // iterations this cycle may still run before -ksp_max_it (known once the report is read)
         int pend_loc = -1;   // ... handed to the cycle-end launch (its Hessenberg column and norm)
         const double *pend_h = nullptr;
         double *pend_n = nullptr;
@@ -1129,10 +1130,16 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
         bool head_done = false, prev_inhead = false;
         auto wl = [&](int p) { return sm + 400 + (p & 1) * 8; };  // lambda entries of w, side copies
         for (int loc = 0; loc < mk && !stop; ++loc) {
-            if (pend_check && loc == kAhead && read_state()) {   // the previous cycle ended the solve: what was enqueued
-                finished = true;                                  // of this one is gated off on the device
-                break;
+            if (pend_check && loc == kAhead) {
+                if (read_state()) {   // the previous cycle ended the solve: what was enqueued of this one is gated off
+                    finished = true;  // on the device
+                    break;
+                }
+                its_cap = (int64_t)o.max_it - st.its;   // (the report is this cycle's cycle_begin: its = iterations before it)
             }
+            // -ksp_max_it ends the solve inside this cycle: the device stops there by itself, the host need not enqueue
+            // (gated) launches beyond it
+            if (loc >= its_cap) break;
             const int32_t *done = &c->kst.p->skip_iter;  // the gate of everything inside an iteration
             double *w = Vj(loc + 1);
             double *db = big ? c->bigdots.p : dotsbuf(loc), *nb = nrmbuf(loc);
