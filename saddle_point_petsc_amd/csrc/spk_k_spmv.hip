@@ -173,7 +173,9 @@ void build_btiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &
 
 // ACC: y += A x (the fused Schur path pre-loads y with B^T lambda); a separate instantiation so
 // that profiles list the plain product (the one bench.py times for the roofline) on its own line
-template <bool NT, bool ACC, bool RIDE>
+// BT: the launch carries B^T lambda rows (MatMult on the nest operator); a template flag because their early fetch costs
+// registers the product without them must not pay (32 against 56 allocated VGPRs: 8 % of its time, section 5 of DESIGN.md)
+template <bool NT, bool ACC, bool RIDE, bool BT>
 __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
     const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
     const double *__restrict__ vtop, const double *__restrict__ vbot,
@@ -249,6 +251,22 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
             bo[i] = ld2s<NT>(vbot, b0 + q);
         }
     }
+    // B^T lambda of this row (MatMult on the nest operator: the restart's true residual, spk_mult): its first entries
+    // are fetched now, behind the matrix stream, not at the end of the kernel (1024^2: 80.2 us against 68.5 for the
+    // product without them); a longer row takes the rest in the row phase
+    constexpr int kBtPre = 4;
+    int kb0 = 0, kb1 = 0;
+    double btv[kBtPre], btl[kBtPre];
+    if (BT && rowok) {
+        kb0 = bt_rowptr[2 * br0 + lr];
+        kb1 = bt_rowptr[2 * br0 + lr + 1];
+#pragma unroll
+        for (int j = 0; j < kBtPre; ++j) {
+            const bool in = kb0 + j < kb1;
+            btv[j] = in ? bt_val[kb0 + j] : 0.0;
+            btl[j] = in ? lam[bt_colidx[kb0 + j]] : 0.0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < kSteps; ++i) {
         const int q = i * kThreads + threadIdx.x;
@@ -276,8 +294,12 @@ __global__ __launch_bounds__(kThreads) void spmv_bcsr_kernel(
         const int r = 2 * br0 + lr;
         if (od.rowptr)  // off-rank columns of this row (ghost values already exchanged)
             for (int k = od.rowptr[r]; k < od.rowptr[r + 1]; ++k) s += od.val[k] * od.xg[od.colidx[k]];
-        if (bt_rowptr)
-            for (int k = bt_rowptr[r]; k < bt_rowptr[r + 1]; ++k) s += bt_val[k] * lam[bt_colidx[k]];
+        if (BT) {
+#pragma unroll
+            for (int j = 0; j < kBtPre; ++j)
+                if (kb0 + j < kb1) s += btv[j] * btl[j];
+            for (int k = kb0 + kBtPre; k < kb1; ++k) s += bt_val[k] * lam[bt_colidx[k]];
+        }
         if (ACC) s += yacc;
         y[r] = s;
     }
@@ -296,16 +318,20 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
     const int nride = rider ? 1 : 0;
     // non-temporal loads on the matrix planes (read once per SpMV): 70.7 -> 61.3 us in the same run
     // (the rider is a template flag: the plain product keeps its registers and its 16 KB of LDS)
-#define SPK_LAUNCH_BCSR(ACC, RIDE)                                                                                         \
-    hipLaunchKernelGGL((spmv_bcsr_kernel<true, ACC, RIDE>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
+#define SPK_LAUNCH_BCSR(ACC, RIDE, BTF)                                                                                         \
+    hipLaunchKernelGGL((spmv_bcsr_kernel<true, ACC, RIDE, BTF>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
                        A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,                \
                        bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
-    if (accumulate) {
-        if (rider) SPK_LAUNCH_BCSR(true, true);
-        else SPK_LAUNCH_BCSR(true, false);
+    if (bt) {   // (MatMult on the nest operator: never the iteration's launch, no rider)
+        if (rider) fail(SPK_ERR_ARG, "spmv_bcsr: B^T rows and a rider in one launch");
+        if (accumulate) SPK_LAUNCH_BCSR(true, false, true);
+        else SPK_LAUNCH_BCSR(false, false, true);
+    } else if (accumulate) {
+        if (rider) SPK_LAUNCH_BCSR(true, true, false);
+        else SPK_LAUNCH_BCSR(true, false, false);
     } else {
-        if (rider) SPK_LAUNCH_BCSR(false, true);
-        else SPK_LAUNCH_BCSR(false, false);
+        if (rider) SPK_LAUNCH_BCSR(false, true, false);
+        else SPK_LAUNCH_BCSR(false, false, false);
     }
 #undef SPK_LAUNCH_BCSR
 }
