@@ -303,6 +303,15 @@ def test_every_iteration_form_against_the_oracle(spk, oracle, form, pc):
             c.set_block(spk.BLOCK_A10, B)
         c.pc_setup(spk.PC_SCHUR if B is not None else spk.PC_JACOBI, 3)
         x, info = c.fgmres(rhs, rtol=1e-9, iteration_form=form)
+        # -ksp_max_it ending the solve in the middle of a cycle (the host stops enqueuing there; the last Givens step
+        # of the form -- a rider, the next head, the cycle end -- must still have run)
+        _, tr = c.fgmres(rhs, rtol=1e-30, max_it=47, iteration_form=form)
+    if B is not None:
+        _, it = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=oracle.SCHUR_FULL, rtol=1e-30, max_it=47)
+    else:
+        _, it = oracle.fgmres(A, rhs, pc_type=oracle.PC_JACOBI, rtol=1e-30, max_it=47)
+    assert tr["its"] == it["its"] == 47 and tr["reason"] == it["reason"] == -3
+    assert np.allclose(tr["history"], it["history"], rtol=1e-6)
     assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 1
     k = min(len(info["history"]), len(io["history"])) - 1
     assert np.allclose(info["history"][:k], io["history"][:k], rtol=1e-6)
