@@ -74,6 +74,9 @@ int spk_create(spk_ctx **out, int device)
         c->device = device;
         SPK_HIP(hipSetDevice(device));
         SPK_HIP(hipStreamCreate(&c->stream));
+        // the solver's state report (pinned block + event): here, not inside the first solve
+        SPK_HIP(hipHostMalloc(&c->pin_state, 512, hipHostMallocDefault));
+        SPK_HIP(hipEventCreateWithFlags(&c->state_ev, hipEventDisableTiming));
         c->comm.reset(spk::make_self_comm());
         c->ensure_scratch();
     } catch (const spk::Error &er) {
