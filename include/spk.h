@@ -84,7 +84,10 @@ typedef struct spk_opts {
     int32_t guess_nonzero;  /* -ksp_initial_guess_nonzero    (0)     */
     int32_t orthog;         /* SPK_ORTHOG_*                  (CGS)   */
     int32_t check_every;    /* host looks at the device convergence word every
-                               this many iterations; 0 = once per restart cycle.
+                               this many iterations (a stream synchronisation each
+                               time); 0 = once per restart cycle, without draining the
+                               stream: the cycle's first kernel reports the state into
+                               pinned memory and the host reads it while the cycle runs.
                                The iterate never depends on it.       */
     int32_t fused;          /* 1: fused PC+operator kernels where the PC allows,
                                0: PCApply and MatMult as separate steps */
