@@ -402,9 +402,9 @@ def main():
         # Schur path (y pre-loaded with B^T lambda: one more vector read), the plain product otherwise.
         "roofline": {"bound": "hbm",
                      "kernel": ({"csr": "spmv_stream_kernel", "bcsr2x2": "spmv_bcsr_kernel", "bcsr3x3": "spmv_bcsr3_kernel"}[spi["format"]])
-                               + ("<.., ACC=true, RIDE=true>: y += A x, as launched by the fused Schur iteration "
+                               + ("<.., ACC=true, RIDE=true[, BT=false]>: y += A x, as launched by the fused Schur iteration "
                                   "(Givens rider in workgroup 0)" if in_solver_acc
-                                  else "<.., ACC=false, RIDE=true>: y = A x, as launched by the iteration"),
+                                  else "<.., ACC=false, RIDE=true[, BT=false]>: y = A x, as launched by the iteration"),
                      "format": spi["format"], "ms": loop_ms,
                      "achieved": loop_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": min(loop_gbps, loop_layout_gbps) / HBM_PEAK_GBS,
