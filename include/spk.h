@@ -131,7 +131,7 @@ typedef struct spk_opts {
     int32_t reserved;
 } spk_opts;
 enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3, SPK_ITER_BA = 4,
-       SPK_ITER_UNNORM = 5 };
+       SPK_ITER_UNNORM = 5, SPK_ITER_LAST = 5 };
 
 typedef struct spk_result {
     int32_t its;            /* KSPGetIterationNumber   */
@@ -262,6 +262,12 @@ int spk_pc_apply(spk_ctx *ctx, const double *x, double *y, int mem);
 int spk_fgmres(spk_ctx *ctx, const double *b, double *x, int mem, const spk_opts *opts,
                spk_result *result, double *history, int32_t history_cap);
 
+/* How the LAST spk_fgmres on ctx launched its iterations: *form = the SPK_ITER_* actually run (AUTO resolved; options
+ * the chosen form does not cover fall back, see spk_opts.iteration_form), or -1 for the step-by-step path (PCApply and
+ * MatMult as launches of their own: unfused preconditioners, FP32 inner sweeps, restart > 62, MGS, CGS refinement);
+ * *single_reduce = 1 when the single-reduction mode ran.  For byte models (bench.py). */
+int spk_get_iteration_form(const spk_ctx *ctx, int32_t *form, int32_t *single_reduce);
+
 /* ---- device vectors for callers that keep b/x resident in HBM --------------- */
 /* (a PCSHELL/MATSHELL glue over device Vecs, bench.py).  Zero-filled, length
  * rounded up so that every kernel may read whole 16-byte pairs. */
@@ -279,6 +285,16 @@ int spk_get_sizes(const spk_ctx *ctx, int64_t *n_global, int32_t *n_local, int32
  * their pattern and columns pair up, as for a dof-2 DMDA; SPK_SPMV_FORMAT=csr forces CSR).
  * layout_bytes = bytes one SpMV reads and writes in that layout (matrix + x + y). */
 int spk_get_spmv_info(const spk_ctx *ctx, int32_t *format, int64_t *layout_bytes);
+/* Formats 3 / 4: ROW-PATTERN DICTIONARY over the 2x2 / 3x3 blocks (the default wherever it exists).  On the reference's
+ * uniform grid (Discretization.c:25; one element matrix for all elements, :293-332) A holds a handful of distinct blocks
+ * in a few dozen distinct block-row sequences; they are found in the caller's CSR at spk_set_block (hashing + a bitwise
+ * verification pass; nothing is assumed about the grid), kept in LDS, and a product then streams x, y and two bytes per
+ * block row -- same products, same order, same bits as the CSR loop.  Matrices whose rows do not repeat keep formats
+ * 0..2; SPK_SPMV_FORMAT=bcsr (or csr) switches the dictionary off.
+ * Byte models of one product y = A x on this rank's diagonal block in the three layouts (0 where a layout does not
+ * exist), and the dictionary's size (distinct block rows, distinct blocks). */
+int spk_get_spmv_models(const spk_ctx *ctx, int64_t *csr_bytes, int64_t *blocked_bytes, int64_t *dict_bytes,
+                        int32_t *patterns, int32_t *blocks);
 
 /* ---- single kernels through the ABI (parity tests, bench.py) -------------- */
 /* h[i] = V_i . w  (i < nv), V given as nv vectors of length n with stride ldv
@@ -293,7 +309,7 @@ int spk_kernel_maxpy(spk_ctx *ctx, int64_t n, int32_t nv, const double *a, const
  * x is a deterministic fill sin(0.37 i). */
 int spk_time_spmv(spk_ctx *ctx, int warmup, int reps, double *ms_per_launch);
 /* Generic form for the other kernels of an iteration (tuning / profiles):
- * which = "spmv" | "spmv_bcsr" | "spmv_acc" | "mult" | "pc" | "mdot" | "maxpy" | "maxpy_nonorm" | "scale" | "wide_dot" |
+ * which = "spmv" | "spmv_bcsr" | "spmv_bcsr3" | "spmv_dict" | "spmv_acc" | "spmv_ride" | "mult" | "pc" | "mdot" | "maxpy" | "maxpy_nonorm" | "scale" | "wide_dot" |
  * "bt_update"; nv = vectors for mdot/maxpy.  Needs operators (and pc_setup for
  * "pc"); allocates its own scratch vectors. */
 int spk_time_kernel(spk_ctx *ctx, const char *which, int nv, int warmup, int reps,

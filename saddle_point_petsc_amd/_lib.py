@@ -114,6 +114,8 @@ def _load():
     L.spk_kernel_maxpy.argtypes = [vp, i64, i32, f64p, f64p, i64, f64p, C.POINTER(dbl)]
     L.spk_time_spmv.argtypes = [vp, C.c_int, C.c_int, C.POINTER(dbl)]
     L.spk_get_spmv_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i64)]
+    L.spk_get_iteration_form.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.spk_get_spmv_models.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
     L.spk_time_kernel.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     L.spk_partition_slab.argtypes = [i64, i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
     L.spk_partition_split.argtypes = [i64, i32, i32p, i32p, f64p] + [vp] * 7 + [C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]

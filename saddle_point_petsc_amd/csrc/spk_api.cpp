@@ -315,13 +315,38 @@ int spk_get_sizes(const spk_ctx *c, int64_t *n_global, int32_t *n_local, int32_t
 int spk_get_spmv_info(const spk_ctx *c, int32_t *format, int64_t *layout_bytes)
 {
     if (!c) return SPK_ERR_ARG;
-    if (format) *format = c->spmv_format;
+    const bool dict = c->spmv_format != 0 && c->Adict.ok;
+    if (format) *format = dict ? 2 + c->spmv_format : c->spmv_format;
     if (layout_bytes) {
         const int64_t n = c->n_local;
-        *layout_bytes = c->spmv_format == 1   ? 36 * c->Ab.nblocks + 4 * ((int64_t)c->Ab.nbrows + 1) + 16 * n
+        *layout_bytes = dict                  ? c->Adict.code_bytes + 2 * (int64_t)c->Adict.nbrows + c->Adict.lds_bytes + 16 * n
+                        : c->spmv_format == 1 ? 36 * c->Ab.nblocks + 4 * ((int64_t)c->Ab.nbrows + 1) + 16 * n
                         : c->spmv_format == 2 ? 76 * c->Ab3.nblocks + 4 * ((int64_t)c->Ab3.nbrows + 1) + 16 * n
                                               : 12 * c->Ad.nnz + 4 * (n + 1) + 16 * n;
     }
+    return SPK_OK;
+}
+
+int spk_get_iteration_form(const spk_ctx *c, int32_t *form, int32_t *single_reduce)
+{
+    if (!c) return SPK_ERR_ARG;
+    if (form) *form = c->last_form;
+    if (single_reduce) *single_reduce = c->last_single;
+    return SPK_OK;
+}
+
+int spk_get_spmv_models(const spk_ctx *c, int64_t *csr_bytes, int64_t *blocked_bytes, int64_t *dict_bytes, int32_t *npat,
+                        int32_t *nblk)
+{
+    if (!c) return SPK_ERR_ARG;
+    const int64_t n = c->n_local;
+    if (csr_bytes) *csr_bytes = 12 * c->Ad.nnz + 4 * (n + 1) + 16 * n;
+    if (blocked_bytes)
+        *blocked_bytes = c->Ab.ok ? 36 * c->Ab.nblocks + 4 * ((int64_t)c->Ab.nbrows + 1) + 16 * n
+                         : c->Ab3.ok ? 76 * c->Ab3.nblocks + 4 * ((int64_t)c->Ab3.nbrows + 1) + 16 * n : 0;
+    if (dict_bytes) *dict_bytes = c->Adict.ok ? c->Adict.code_bytes + 2 * (int64_t)c->Adict.nbrows + c->Adict.lds_bytes + 16 * n : 0;
+    if (npat) *npat = c->Adict.ok ? c->Adict.ntype : 0;
+    if (nblk) *nblk = c->Adict.ok ? c->Adict.nclass : 0;
     return SPK_OK;
 }
 
@@ -496,9 +521,7 @@ int spk_time_spmv(spk_ctx *c, int warmup, int reps, double *ms_per_launch)
     SPK_HIP(hipEventCreate(&e0));
     SPK_HIP(hipEventCreate(&e1));
     auto one = [&]() {  // the kernel the solver launches for the A block
-        if (c->spmv_format == 2) spk::k::spmv_bcsr3(c->Ab3, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
-        else if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
-        else spk::k::spmv(c->Ad, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, c->stream);
+        spk::a_mult(c, c->stage_x.p, c->stage_y.p, nullptr, nullptr, nullptr, false, nullptr);
     };
     for (int i = 0; i < warmup; ++i) one();
     SPK_HIP(hipEventRecord(e0, c->stream));
@@ -538,6 +561,8 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
     hipStream_t s = c->stream;
     auto run = [&]() {
         if (w == "spmv") spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s);
+        else if (w == "spmv_bcsr3") { if (!c->Ab3.ok) spk::fail(SPK_ERR_STATE, "no 3x3-blocked copy"); spk::k::spmv_bcsr3(c->Ab3, x, y, nullptr, nullptr, nullptr, s); }
+        else if (w == "spmv_dict") { if (!c->Adict.ok) spk::fail(SPK_ERR_STATE, "no row-type layout"); spk::k::spmv_dict(c->Adict, x, y, nullptr, nullptr, nullptr, s); }
         else if (w == "spmv_bcsr") { if (!c->Ab.ok) spk::fail(SPK_ERR_STATE, "no 2x2-blocked copy"); spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s); }
         else if (w == "spmv_acc" || w == "spmv_ride") {
             // y += A x (spmv_ride: y = A x) in the active format, as the default iteration launches it: with the Givens
@@ -545,9 +570,7 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
             spk::k::GivensRider gr{c->ka, 0, c->small.p, c->small.p + 64, nullptr, nullptr, 0, spk::k::FinErr{nullptr, 0}, spk::k::PeerAR{}};
             const spk::k::GivensRider *rp = c->kst.p ? &gr : nullptr;
             const bool acc = w == "spmv_acc";
-            if (c->spmv_format == 2) spk::k::spmv_bcsr3(c->Ab3, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
-            else if (c->spmv_format == 1) spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
-            else spk::k::spmv(c->Ad, x, y, nullptr, nullptr, nullptr, s, acc, nullptr, rp);
+            spk::a_mult(c, x, y, nullptr, nullptr, nullptr, acc, nullptr, rp);
         }
         else if (w == "mult") spk::op_mult(c, x, y, nullptr);
         else if (w == "pc") { if (!c->pc_ready) spk::fail(SPK_ERR_STATE, "pc not set up"); spk::op_pc_apply(c, x, y, nullptr); }

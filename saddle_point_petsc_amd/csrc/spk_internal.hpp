@@ -130,6 +130,34 @@ struct Bcsr3Dev {
     bool ok = false;
 };
 
+// Row types + deviation codes of a blocked matrix (bs = 2 or 3; spk_k_dict.hip).  The reference assembles the same
+// element matrix for every element of a uniform grid (/root/reference/src/Discretization.c:25, :293-332) -- up to the
+// rounding of a Jacobian formed from node coordinates (:96-128): the entries of A scatter by a few hundred ulps around a
+// handful of ideal values.  So A has a few dozen block CLASSES (blocks equal up to that noise) and a few dozen ROW TYPES
+// (sequences of (column offset, class) along a block row).  Stored per block row: one 16-bit type; per stored value: a
+// 16-bit (where a class scatters wider: 32-bit) integer k with  value = base[class][entry] + k 2^g[class][entry]  exactly.
+// The two small tables sit in LDS.  A product streams x, y and ~2.1 B per stored non-zero instead of 9 (blocked) / 12
+// (CSR) and forms the same products in the same order: bit-identical sums.  Found in the caller's CSR at KSPSetOperators
+// (hashing on the device, then EVERY value decoded and compared bit by bit); a matrix that does not fit (too many classes
+// or types, a row beyond kDictMaxK blocks, deviations that are not small multiples of one power of two, tables beyond the
+// LDS budget) keeps the plain blocked layout.
+constexpr int kDictMaxK = 32;      // blocks per block row
+struct DictDev {
+    int bs = 0;
+    int32_t nbrows = 0, ntype = 0, nclass = 0, kmax = 0;
+    int64_t nblocks = 0;
+    DevBuf<uint16_t> tid;          // type of every block row
+    DevBuf<int32_t> tab;           // [ntype] lengths (padded to an even count), then ntype x kmax x {column offset, class}
+    DevBuf<double> cls;            // nclass x bs*bs x {base, 2^g}
+    DevBuf<unsigned char> codes;   // per block position k: a plane of 16-bit low halves (nbrows x 8 | 24 bytes for bs = 2 | 3), and behind it,
+                                   // for a position with 32-bit codes, a plane of high halves: code = sext(low) + (high << 16)
+    int64_t plane_off[kDictMaxK] = {};
+    uint32_t wide_mask = 0;        // bit k: position k holds 32-bit codes
+    int64_t code_bytes = 0;        // bytes of codes a product reads (the planes without their padding rows)
+    int32_t lds_bytes = 0;         // tables as laid out in LDS
+    bool ok = false;
+};
+
 // Short-and-wide block (B: m rows x n_local cols) cut into column windows so
 // that x is streamed once for all m rows.
 struct WideDev {
@@ -366,6 +394,29 @@ void spmv_bcsr3(const Bcsr3Dev &A, const double *x, double *y, const CsrDev *bt,
                 const int32_t *done, hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr,
                 const GivensRider *rider = nullptr);
 void build_b3tiles(const int32_t *browptr, int32_t nbrows, std::vector<int32_t> &tile_brow);
+// ... and from row types + deviation codes (spk_k_dict.hip; same sums once more)
+constexpr int kDictMaxPat = 1024, kDictMaxBlk = 1024, kDictSlots = 8192, kDictLdsMax = 48 * 1024;
+void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done,
+               hipStream_t s, bool accumulate = false, const OffDiag *od = nullptr, const GivensRider *rider = nullptr);
+void jacobi_sweep_f32_dict(const DictDev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                           const int32_t *done, hipStream_t s);
+// set-up passes: classes by hashing (keys/rep: kDictSlots entries, zero / INT32_MAX before the call; slot: the table
+// slot of every item; ctl[0] = number of distinct keys, ctl[1] = 1 when there are too many)
+void dict_hash_blocks(int bs, const double *v0, const double *v1, int64_t ldp, int64_t nblocks, unsigned long long *keys,
+                      int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys, hipStream_t s);
+// cls[(id, e)] = {entry e of block rep_of_id[id], 1}; slot[q] -> class number; gexp / dmax: per (class, entry) the finest
+// bit and the largest magnitude of value - base (INT32_MAX / 0 before the call); *bad: a deviation that is not exact
+void dict_class_stats(int bs, const double *v0, const double *v1, int64_t ldp, int64_t nblocks, const int32_t *rep_of_id, int nid,
+                      const int32_t *slot2id, int32_t *slot, double *cls, int32_t *gexp, unsigned long long *dmax, int32_t *bad,
+                      hipStream_t s);
+void dict_hash_rows(const int32_t *browptr, const int32_t *bcol, const int32_t *blkid, int32_t nbrows, unsigned long long *keys,
+                    int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys, int kmax, hipStream_t s);
+void dict_fill_rows(const int32_t *browptr, const int32_t *bcol, const int32_t *blkid, int32_t nbrows, const int32_t *rep_of_id,
+                    int nid, int kmax, const int32_t *slot2id, const int32_t *slot, int32_t *tab, uint16_t *tid, int32_t *bad,
+                    hipStream_t s);
+// writes the code planes of A (tables, plane offsets and widths set), then decodes every value and compares its bits
+void dict_encode_verify(const DictDev &A, const int32_t *browptr, const int32_t *bcol, const int32_t *blkid, const double *v0,
+                        const double *v1, int64_t ldp, int32_t *bad, hipStream_t s);
 void bcsr3_fill(const int32_t *rp, const int32_t *ci, const double *va, int nbr, int32_t *browptr, int32_t *bcol, double *v,
                 int64_t ldp, int32_t *fail, hipStream_t s);
 void jacobi_sweep_f32_b2(const BcsrDev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
@@ -609,8 +660,6 @@ struct IterBA {
     KrylovArrays ka;
     int loc;
     const int32_t *done;
-    unsigned long long *dbg;  // SPK_BA_DEBUG: 100 MHz time stamps of workgroup dbg_wg (nullptr: off)
-    int dbg_wg;
 };
 void iter_ba(const IterBA &p, hipStream_t s);
 // block-column range of every tile of the blocked matrix (set-up of the BA kernel's neighbour lists)
@@ -668,6 +717,7 @@ struct spk_ctx {
     spk::BcsrDev Ab;               // 2x2-blocked copy of Ad when the structure allows
     int spmv_format = 0;           // 0 = CSR stream kernel, 1 = 2x2 blocks (Ab), 2 = 3x3 blocks (Ab3)
     spk::Bcsr3Dev Ab3;             // 3x3-blocked copy (dof-3 grids)
+    spk::DictDev Adict;            // row types + deviation codes over the blocked copy (uniform grids); Adict.ok: the products use it
     spk::DevBuf<int32_t> ao_rows;  // local row of each compressed Ao row
     spk::DevBuf<int32_t> ao_rowptr_full;  // Ao row pointers over all local rows (SpMV epilogue form)
     spk::k::SendRanges send_ranges{};     // halo rows as contiguous ranges, when they are
@@ -717,6 +767,10 @@ struct spk_ctx {
     void check_device_error();
     spk::DevBuf<double> y1tmp, ttmp;
 
+    // how the last spk_fgmres launched its iterations (spk_get_iteration_form): SPK_ITER_* actually run, -1 for the
+    // step-by-step path (PCApply and MatMult as launches of their own); single-reduction mode beside it
+    int last_form = -1, last_single = 0;
+
     // Krylov workspace (sized by restart)
     int ws_restart = -1;
     spk::DevBuf<double> V, Z, xsol, rhs, tmp;
@@ -743,6 +797,9 @@ struct spk_ctx {
 
 namespace spk {
 // solver pieces used by the API layer (spk_solver.cpp)
+// y (+)= Ad x in the layout the context holds: row types + codes, 2x2 / 3x3 blocks or CSR (same sums in all of them)
+void a_mult(spk_ctx *c, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done, bool accumulate,
+            const k::OffDiag *od, const k::GivensRider *rider = nullptr);
 void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool halo_done = false);
 void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done);
 void pc_setup(spk_ctx *c, int pc_type, int schur_fact);

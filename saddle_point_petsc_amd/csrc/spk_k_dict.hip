@@ -1,0 +1,675 @@
+// spk_k_dict.hip -- MatMult on the A block from ROW TYPES + DEVIATION CODES (DictDev, spk_internal.hpp), the FP32 Richardson
+// sweep on the same layout, and the set-up passes that find the layout.  gfx950, wave64.
+//
+// Why: MatMult_SeqAIJ streams 12 B per stored non-zero (494 MB per product at 1024^2), the 2x2-blocked copy 9 B.  The
+// reference assembles the SAME element matrix for every element of a uniform grid
+// (/root/reference/src/Discretization.c:25, :293-332) -- up to rounding: the Jacobian is formed from node coordinates
+// i*h (:96-128), so the entries of A scatter by a few hundred ulps around a handful of ideal values (measured at 1024^2:
+// 34 185 distinct doubles, 7 ideal values; > 58 000 distinct 2x2 blocks at 256^2 already -- a dictionary of exact blocks
+// does not exist).  What repeats is the block up to that noise (a few dozen CLASSES) and the sequence of (column offset,
+// class) along a block row (a few dozen ROW TYPES).  Stored: one 16-bit type per block row, the two small tables (in LDS),
+// and per stored value a 16-bit integer k with   value = base[class][entry] + k * 2^g[class][entry]   EXACTLY (32-bit k
+// where a class scatters wider).  2.1 B per stored non-zero instead of 9 / 12; decoding is one integer conversion and one
+// FMA whose result is exact, so the products and their order -- hence every bit of the sums -- are those of the CSR loop.
+// Nothing is assumed about the grid: classes and types are FOUND in the caller's CSR by hashing, the codes are verified
+// by decoding every value and comparing its bits, and a matrix that does not fit (too many classes / types, deviations
+// that are not small multiples of one power of two) keeps the blocked / CSR kernels.
+//
+// Parity: a row type lists its blocks in the block row's CSR order; every product is rounded on its own (contraction off)
+// and added in that order, starting from +0: bit-identical to spmv_bcsr_kernel, the CSR kernel and the oracle
+// (tests/test_gpu_parity.py::test_spmv_A_block_bitwise, tests/test_gpu_dict.py).
+#include "spk_device.hpp"
+
+#include <climits>
+
+namespace spk {
+namespace k {
+
+constexpr int kDictChunk = kThreads;   // block rows per chunk: one per thread
+typedef int int2v __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------
+// the product
+// ---------------------------------------------------------------------------
+struct DictArgs {
+    const uint16_t *tid;
+    const int32_t *tab;
+    const double *cls;             // nclass x bs*bs x {base, scale}
+    const unsigned char *codes;
+    int32_t nbrows, ntype, nclass, kmax;
+    int64_t nbrows_pad;            // rows of a code plane (nbrows rounded up to 16); a wide position has two planes
+    int32_t nchunks, chunks_per_xcd, chunks_per_wg;
+    int32_t tab_ints, cls_off;     // ints of the type tables; byte offset of the class table in LDS
+    uint32_t wide_mask;            // bit k: position k of a block row holds 32-bit codes
+    int64_t plane_off[kDictMaxK];  // byte offset of the code plane of position k
+};
+
+// bytes of one block's 16-bit halves in a plane: bs = 2 -- four in 8 bytes; bs = 3 -- three rows of three, each row in 8
+__host__ __device__ constexpr int dict_block_bytes(int bs) { return bs == 2 ? 8 : 24; }
+
+// tables -> LDS (every workgroup; a few KB out of L2)
+__device__ __forceinline__ void dict_load_lds(const DictArgs &d, int nclsvals, char *smem)
+{
+    int32_t *ti = reinterpret_cast<int32_t *>(smem);
+    for (int i = threadIdx.x; i < d.tab_ints; i += kThreads) ti[i] = d.tab[i];
+    double2 *cv = reinterpret_cast<double2 *>(smem + d.cls_off);
+    const double2 *src = reinterpret_cast<const double2 *>(d.cls);
+    for (int i = threadIdx.x; i < nclsvals; i += kThreads) cv[i] = src[i];
+    __syncthreads();
+}
+
+// The codes of block position k of block row br, as stored: every position has a plane of 16-bit LOW halves (bs = 2:
+// four in 8 bytes; bs = 3: three rows of three, each row in 8 bytes); a WIDE position has a second plane of the same
+// shape with the high halves, adjusted so that code = sext(low) + (high << 16) needs no case distinction.  Narrow
+// positions leave `hi` at zero.  The loads are issued here, unconditionally but for the one uniform test, and unpacked
+// later (dict_unpack): nothing below waits for memory, so a row's loads are all in flight together.
+template <int BS>
+struct DictRaw {
+    int2v lo[BS == 2 ? 1 : 3], hi[BS == 2 ? 1 : 3];
+};
+template <int BS>
+__device__ __forceinline__ void dict_issue(const DictArgs &d, int k, int64_t br, DictRaw<BS> &w)
+{
+    constexpr int R = BS == 2 ? 1 : 3;
+    const bool wide = (d.wide_mask >> k) & 1u;
+    const int2v *p = reinterpret_cast<const int2v *>(d.codes + d.plane_off[k]) + R * br;
+#pragma unroll
+    for (int r = 0; r < R; ++r) w.lo[r] = __builtin_nontemporal_load(p + r);
+#pragma unroll
+    for (int r = 0; r < R; ++r) w.hi[r] = int2v{0, 0};
+    if (wide) {
+        const int2v *q = p + (int64_t)R * d.nbrows_pad;
+#pragma unroll
+        for (int r = 0; r < R; ++r) w.hi[r] = __builtin_nontemporal_load(q + r);
+    }
+}
+template <int BS>
+__device__ __forceinline__ void dict_unpack(const DictRaw<BS> &w, int (&c)[BS * BS])
+{
+    constexpr int R = BS == 2 ? 1 : 3;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int l0 = (int)(short)(w.lo[r].x & 0xffff), l1 = w.lo[r].x >> 16, l2 = (int)(short)(w.lo[r].y & 0xffff), l3 = w.lo[r].y >> 16;
+        const int h0 = (int)(short)(w.hi[r].x & 0xffff), h1 = w.hi[r].x >> 16, h2 = (int)(short)(w.hi[r].y & 0xffff), h3 = w.hi[r].y >> 16;
+        if (BS == 2) {
+            c[0] = l0 + h0 * 65536;
+            c[1] = l1 + h1 * 65536;
+            c[2] = l2 + h2 * 65536;
+            c[3] = l3 + h3 * 65536;
+        } else {
+            c[3 * r] = l0 + h0 * 65536;
+            c[3 * r + 1] = l1 + h1 * 65536;
+            c[3 * r + 2] = l2 + h2 * 65536;
+        }
+    }
+}
+// value = base + k * 2^g: both terms exact, the sum representable (it is the stored value): exact under any rounding
+__device__ __forceinline__ double dict_decode(int code, double2 bs)
+{
+    return __builtin_fma((double)code, bs.y, bs.x);
+}
+
+template <int BS, bool ACC, bool RIDE, bool BT>
+__global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
+                                                             const int32_t *__restrict__ bt_rowptr,
+                                                             const int32_t *__restrict__ bt_colidx,
+                                                             const double *__restrict__ bt_val, const double *__restrict__ lam,
+                                                             OffDiag od, const int32_t *__restrict__ done, GivensRider gr)
+{
+#pragma clang fp contract(off)  // every product rounded on its own, as in the CSR loop the sums are compared with
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (RIDE && blockIdx.x == 0) {  // the rider: a pending Givens step beside the row chunks (its LDS: the table space)
+        givens_rider(gr, reinterpret_cast<double *>(smem));
+        return;
+    }
+    const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
+    // workgroups b, b+8, ... share an XCD: each XCD gets a contiguous run of chunks, so the x window stays in ITS L2
+    const int c0 = ((bx & 7) * d.chunks_per_xcd + (bx >> 3) * d.chunks_per_wg);
+    const int c1 = min(min(c0 + d.chunks_per_wg, ((bx & 7) + 1) * d.chunks_per_xcd), d.nchunks);
+    if (c0 >= c1) return;
+    // what does not depend on the tables is requested before they are copied
+    int br = c0 * kDictChunk + (int)threadIdx.x;
+    int tidn = br < d.nbrows ? (int)d.tid[br] : -1;
+    dict_load_lds(d, d.nclass * BS * BS, smem);
+    const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
+    const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
+    const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);
+
+    for (int ch = c0; ch < c1; ++ch) {
+        const int tc = tidn;
+        const int brc = br;
+        br += kDictChunk;
+        tidn = (ch + 1 < c1 && br < d.nbrows) ? (int)d.tid[br] : -1;   // next chunk's row type: in flight during this one
+        if (tc < 0) continue;
+        double s[BS];
+#pragma unroll
+        for (int r = 0; r < BS; ++r) s[r] = 0.0;
+        double yacc[BS];
+        if (ACC) {
+            if (BS == 2) {
+                const double2 t = reinterpret_cast<const double2 *>(y)[brc];
+                yacc[0] = t.x;
+                yacc[1] = t.y;
+            } else {
+#pragma unroll
+                for (int r = 0; r < BS; ++r) yacc[r] = y[(int64_t)BS * brc + r];
+            }
+        }
+        // B^T lambda of these rows (MatMult on the nest operator): first entries requested early (see spmv_bcsr_kernel)
+        constexpr int kBtPre = 4;
+        int kb0[BS], kb1[BS];
+        double btv[BS][kBtPre], btl[BS][kBtPre];
+        if (BT) {
+#pragma unroll
+            for (int r = 0; r < BS; ++r) {
+                kb0[r] = bt_rowptr[(int64_t)BS * brc + r];
+                kb1[r] = bt_rowptr[(int64_t)BS * brc + r + 1];
+#pragma unroll
+                for (int j = 0; j < kBtPre; ++j) {
+                    const bool in = kb0[r] + j < kb1[r];
+                    btv[r][j] = in ? bt_val[kb0[r] + j] : 0.0;
+                    btl[r][j] = in ? lam[bt_colidx[kb0[r] + j]] : 0.0;
+                }
+            }
+        }
+        const int len = tlen[tc];
+        const int2 *te = tent + (size_t)tc * d.kmax;
+        constexpr int G = BS == 2 ? 9 : 3;   // blocks whose loads are in flight together (a 2-D interior row: all nine)
+        for (int k0 = 0; k0 < len; k0 += G) {
+            int2 e[G];
+            DictRaw<BS> raw[G];
+            double xv[G][BS];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool in = k0 + g < len;
+                e[g] = in ? te[k0 + g] : make_int2(0, 0);
+                if (in) {
+                    dict_issue<BS>(d, k0 + g, brc, raw[g]);
+                    const int64_t c = (int64_t)brc + e[g].x;
+                    if (BS == 2) {
+                        const double2 t = reinterpret_cast<const double2 *>(x)[c];
+                        xv[g][0] = t.x;
+                        xv[g][1] = t.y;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < BS; ++j) xv[g][j] = x[BS * c + j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (k0 + g < len) {
+                    const double2 *cb = cv + (size_t)e[g].y * (BS * BS);
+                    int code[BS * BS];
+                    dict_unpack<BS>(raw[g], code);
+#pragma unroll
+                    for (int r = 0; r < BS; ++r)
+#pragma unroll
+                        for (int j = 0; j < BS; ++j) s[r] += dict_decode(code[r * BS + j], cb[r * BS + j]) * xv[g][j];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            const int64_t row = (int64_t)BS * brc + r;
+            // (off-rank and B^T terms: fused multiply-adds, as the compiler contracts them in the blocked and CSR kernels --
+            // every layout gives the same bits on these rows too)
+            if (od.rowptr)  // off-rank columns of this row (ghost values already exchanged)
+                for (int k = od.rowptr[row]; k < od.rowptr[row + 1]; ++k) s[r] = __builtin_fma(od.val[k], od.xg[od.colidx[k]], s[r]);
+            if (BT) {
+#pragma unroll
+                for (int j = 0; j < kBtPre; ++j)
+                    if (kb0[r] + j < kb1[r]) s[r] = __builtin_fma(btv[r][j], btl[r][j], s[r]);
+                for (int k = kb0[r] + kBtPre; k < kb1[r]; ++k) s[r] = __builtin_fma(bt_val[k], lam[bt_colidx[k]], s[r]);
+            }
+            if (ACC) s[r] += yacc[r];
+        }
+        if (BS == 2) {
+            double2 o;
+            o.x = s[0];
+            o.y = s[1];
+            reinterpret_cast<double2 *>(y)[brc] = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < BS; ++r) y[(int64_t)BS * brc + r] = s[r];
+        }
+    }
+}
+
+static DictArgs dict_args(const DictDev &A, int *grid)
+{
+    DictArgs d{};
+    d.tid = A.tid.p;
+    d.tab = A.tab.p;
+    d.cls = A.cls.p;
+    d.codes = A.codes.p;
+    d.nbrows = A.nbrows;
+    d.ntype = A.ntype;
+    d.nclass = A.nclass;
+    d.kmax = A.kmax;
+    d.nbrows_pad = ((int64_t)A.nbrows + 15) & ~(int64_t)15;
+    d.nchunks = (A.nbrows + kDictChunk - 1) / kDictChunk;
+    // large systems: a few chunks per workgroup (the table copy is paid once per workgroup), about 2048 workgroups
+    d.chunks_per_wg = std::max(1, d.nchunks / 2048);
+    const int cpx = (d.nchunks + 7) / 8;
+    d.chunks_per_xcd = (cpx + d.chunks_per_wg - 1) / d.chunks_per_wg * d.chunks_per_wg;
+    d.tab_ints = ((A.ntype + 1) & ~1) + 2 * A.ntype * A.kmax;
+    d.cls_off = (4 * d.tab_ints + 15) & ~15;
+    d.wide_mask = A.wide_mask;
+    for (int k = 0; k < kDictMaxK; ++k) d.plane_off[k] = A.plane_off[k];
+    *grid = 8 * (d.chunks_per_xcd / d.chunks_per_wg);
+    return d;
+}
+
+void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done,
+               hipStream_t s, bool accumulate, const OffDiag *odp, const GivensRider *rider)
+{
+    if (A.nbrows == 0) {
+        if (rider) givens_rider_alone(*rider, done, s);
+        return;
+    }
+    int grid = 0;
+    const DictArgs d = dict_args(A, &grid);
+    const OffDiag od = odp ? *odp : OffDiag{nullptr, nullptr, nullptr, nullptr};
+    const GivensRider gr = rider ? *rider : no_rider();
+    const int nride = rider ? 1 : 0;
+    // LDS: the tables; a launch with a rider needs the rider's scratch in block 0
+    size_t lds = (size_t)A.lds_bytes;
+    if (rider) lds = std::max(lds, sizeof(double) * (size_t)(kThreads + 4 * (kMaxNv + 2) + 4));
+#define SPK_LAUNCH_DICT(BS, ACC, RIDE, BTF)                                                                                     \
+    hipLaunchKernelGGL((spmv_dict_kernel<BS, ACC, RIDE, BTF>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,             \
+                       bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
+#define SPK_DISPATCH_DICT(BS)                                                                                                   \
+    if (bt) {                                                                                                                   \
+        if (rider) fail(SPK_ERR_ARG, "spmv_dict: B^T rows and a rider in one launch");                                         \
+        if (accumulate) SPK_LAUNCH_DICT(BS, true, false, true);                                                                 \
+        else SPK_LAUNCH_DICT(BS, false, false, true);                                                                           \
+    } else if (accumulate) {                                                                                                    \
+        if (rider) SPK_LAUNCH_DICT(BS, true, true, false);                                                                      \
+        else SPK_LAUNCH_DICT(BS, true, false, false);                                                                           \
+    } else {                                                                                                                    \
+        if (rider) SPK_LAUNCH_DICT(BS, false, true, false);                                                                     \
+        else SPK_LAUNCH_DICT(BS, false, false, false);                                                                          \
+    }
+    if (A.bs == 2) { SPK_DISPATCH_DICT(2) }
+    else { SPK_DISPATCH_DICT(3) }
+#undef SPK_DISPATCH_DICT
+#undef SPK_LAUNCH_DICT
+}
+
+// ---------------------------------------------------------------------------
+// FP32 damped-Jacobi Richardson sweep on the same layout (see jacobi_sweep_f32_kernel in spk_k_spmv.hip): the value is
+// decoded exactly, rounded to single precision (= the float copy the other sweep kernels read), products rounded once
+// each, summed per row in block order = CSR order -- the same bits as the CSR sweep and the oracle's float loop.
+// ---------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArgs d, const float *__restrict__ d32, float omega,
+                                                                         const float *__restrict__ x32,
+                                                                         const float *__restrict__ yin, float *__restrict__ yout,
+                                                                         const int32_t *__restrict__ done)
+{
+#pragma clang fp contract(off)  // every product and sum below is rounded on its own (the oracle's float loop)
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bx = (int)blockIdx.x;
+    const int c0 = ((bx & 7) * d.chunks_per_xcd + (bx >> 3) * d.chunks_per_wg);
+    const int c1 = min(min(c0 + d.chunks_per_wg, ((bx & 7) + 1) * d.chunks_per_xcd), d.nchunks);
+    if (c0 >= c1) return;
+    dict_load_lds(d, d.nclass * BS * BS, smem);
+    const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
+    const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
+    const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);
+    for (int ch = c0; ch < c1; ++ch) {
+        const int br = ch * kDictChunk + (int)threadIdx.x;
+        if (br >= d.nbrows) continue;
+        const int tc = (int)d.tid[br];
+        float s[BS];
+#pragma unroll
+        for (int r = 0; r < BS; ++r) s[r] = 0.0f;
+        const int len = tlen[tc];
+        const int2 *te = tent + (size_t)tc * d.kmax;
+        constexpr int G = BS == 2 ? 9 : 3;
+        for (int k0 = 0; k0 < len; k0 += G) {
+            int2 e[G];
+            DictRaw<BS> raw[G];
+            float yv[G][BS];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool in = k0 + g < len;
+                e[g] = in ? te[k0 + g] : make_int2(0, 0);
+                if (in) {
+                    dict_issue<BS>(d, k0 + g, br, raw[g]);
+                    const int64_t c = (int64_t)br + e[g].x;
+#pragma unroll
+                    for (int j = 0; j < BS; ++j) yv[g][j] = yin[BS * c + j];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (k0 + g < len) {
+                    const double2 *cb = cv + (size_t)e[g].y * (BS * BS);
+                    int code[BS * BS];
+                    dict_unpack<BS>(raw[g], code);
+#pragma unroll
+                    for (int r = 0; r < BS; ++r)
+#pragma unroll
+                        for (int j = 0; j < BS; ++j) s[r] = (s[r] + ((float)dict_decode(code[r * BS + j], cb[r * BS + j]) * yv[g][j]));
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            const int64_t row = (int64_t)BS * br + r;
+            yout[row] = yin[row] + ((omega * d32[row]) * (x32[row] - s[r]));
+        }
+    }
+}
+
+void jacobi_sweep_f32_dict(const DictDev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                           const int32_t *done, hipStream_t s)
+{
+    if (A.nbrows == 0) return;
+    int grid = 0;
+    const DictArgs d = dict_args(A, &grid);
+    if (A.bs == 2)
+        hipLaunchKernelGGL((jacobi_sweep_f32_dict_kernel<2>), dim3(grid), dim3(kThreads), (size_t)A.lds_bytes, s, d, d32, omega, x32,
+                           yin, yout, done);
+    else
+        hipLaunchKernelGGL((jacobi_sweep_f32_dict_kernel<3>), dim3(grid), dim3(kThreads), (size_t)A.lds_bytes, s, d, d32, omega, x32,
+                           yin, yout, done);
+}
+
+// ---------------------------------------------------------------------------
+// set-up: block classes (blocks equal up to rounding noise), then row types (the sequence of column offset and class
+// along a block row), proposed by hashing into a small open-addressing table; then the per-entry granule and range of
+// every class, the codes, and a verification pass that decodes EVERY value and compares its bits with the original.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h, unsigned long long w)
+{
+    h ^= w + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
+    return h;
+}
+// slot of key h (claimed if new); -1: table full / too many keys (ctl[1] raised)
+__device__ __forceinline__ int dict_insert(unsigned long long h, int32_t item, unsigned long long *keys, int32_t *rep,
+                                           int32_t *ctl, int maxkeys)
+{
+    if (h == 0ull) h = 1ull;
+    int idx = (int)(h & (unsigned long long)(kDictSlots - 1));
+    for (int probe = 0; probe < kDictSlots; ++probe) {
+        if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+        unsigned long long prev = __hip_atomic_load(keys + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0ull) {
+            prev = atomicCAS(keys + idx, 0ull, h);
+            if (prev == 0ull && atomicAdd(ctl, 1) + 1 > maxkeys) {
+                __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return -1;
+            }
+        }
+        if (prev == 0ull || prev == h) {
+            // (millions of items fall into a few dozen classes: the atomic only where it would change something)
+            if (item < __hip_atomic_load(rep + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(rep + idx, item);
+            return idx;
+        }
+        idx = (idx + 1) & (kDictSlots - 1);
+    }
+    __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return -1;
+}
+
+// value (r, j) of block q: bs = 2 -- v0 = (a00, a01) pairs, v1 = (a10, a11) pairs; bs = 3 -- nine planes of stride ldp in v0
+template <int BS>
+__device__ __forceinline__ double blk_val(const double *v0, const double *v1, int64_t ldp, int64_t q, int r, int j)
+{
+    if (BS == 2) return (r == 0 ? v0 : v1)[2 * q + j];
+    return v0[(int64_t)(3 * r + j) * ldp + q];
+}
+// what two values of one class agree in: the value to about 1e-6 absolute (far above the assembly's rounding noise, far
+// below the distance of the ideal entries); huge or non-finite values only match themselves
+__device__ __forceinline__ unsigned long long coarse_key(double v)
+{
+    if (!(fabs(v) < 1e12)) return (unsigned long long)__double_as_longlong(v);
+    return (unsigned long long)(long long)rint(v * 1048576.0);
+}
+
+template <int BS>
+__global__ __launch_bounds__(kThreads) void dict_hash_blocks_kernel(const double *__restrict__ v0, const double *__restrict__ v1,
+                                                                    int64_t ldp, int64_t nblocks, unsigned long long *keys,
+                                                                    int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys)
+{
+    const int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (q >= nblocks) return;
+    unsigned long long h = 0x243F6A8885A308D3ull;
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) h = mix64(h, coarse_key(blk_val<BS>(v0, v1, ldp, q, r, j)));
+    slot[q] = dict_insert(h, (int32_t)q, keys, rep, ctl, maxkeys);
+}
+void dict_hash_blocks(int bs, const double *v0, const double *v1, int64_t ldp, int64_t nblocks, unsigned long long *keys,
+                      int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys, hipStream_t s)
+{
+    if (nblocks == 0) return;
+    const unsigned grid = (unsigned)((nblocks + kThreads - 1) / kThreads);
+    if (bs == 2) hipLaunchKernelGGL((dict_hash_blocks_kernel<2>), dim3(grid), dim3(kThreads), 0, s, v0, v1, ldp, nblocks, keys, rep, slot, ctl, maxkeys);
+    else hipLaunchKernelGGL((dict_hash_blocks_kernel<3>), dim3(grid), dim3(kThreads), 0, s, v0, v1, ldp, nblocks, keys, rep, slot, ctl, maxkeys);
+}
+
+// cls[(id, e)].base = entry e of the class's first block
+template <int BS>
+__global__ __launch_bounds__(kThreads) void dict_cls_base_kernel(const double *__restrict__ v0, const double *__restrict__ v1,
+                                                                 int64_t ldp, const int32_t *__restrict__ rep_of_id, int nid,
+                                                                 double *__restrict__ cls)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= nid * BS * BS) return;
+    const int id = i / (BS * BS), e = i % (BS * BS);
+    cls[2 * i] = blk_val<BS>(v0, v1, ldp, rep_of_id[id], e / BS, e % BS);
+    cls[2 * i + 1] = 1.0;
+}
+// slot[q] -> class number; per (class, entry): the finest bit any deviation from the base uses (gexp, atomicMin) and the
+// largest deviation (bits of |d|, atomicMax).  *bad: a deviation that is not exactly representable
+template <int BS>
+__global__ __launch_bounds__(kThreads) void dict_cls_stats_kernel(const double *__restrict__ v0, const double *__restrict__ v1,
+                                                                  int64_t ldp, int64_t nblocks, const int32_t *__restrict__ slot2id,
+                                                                  int32_t *__restrict__ slot, const double *__restrict__ cls,
+                                                                  int32_t *__restrict__ gexp, unsigned long long *__restrict__ dmax,
+                                                                  int32_t *__restrict__ bad)
+{
+    const int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (q >= nblocks) return;
+    const int sl = slot[q];
+    const int id = sl >= 0 ? slot2id[sl] : -1;
+    slot[q] = id;
+    if (id < 0) {
+        *bad = 1;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+            const int e = r * BS + j;
+            const double v = blk_val<BS>(v0, v1, ldp, q, r, j), base = cls[2 * (id * BS * BS + e)];
+            const double dv = v - base;
+            if (__double_as_longlong(base + dv) != __double_as_longlong(v) || !(fabs(dv) < 1e300)) {
+                *bad = 1;
+                continue;
+            }
+            if (dv == 0.0) continue;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(fabs(dv));
+            const int ef = (int)(bits >> 52);
+            const unsigned long long mant = (bits & 0xFFFFFFFFFFFFFull) | (ef ? 0x10000000000000ull : 0ull);
+            const int low = (ef ? ef - 1075 : -1074) + (int)__builtin_ctzll(mant);   // exponent of the lowest set bit
+            if (low < __hip_atomic_load(gexp + id * BS * BS + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(gexp + id * BS * BS + e, low);
+            if (bits > __hip_atomic_load(dmax + id * BS * BS + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dmax + id * BS * BS + e, bits);
+        }
+}
+void dict_class_stats(int bs, const double *v0, const double *v1, int64_t ldp, int64_t nblocks, const int32_t *rep_of_id, int nid,
+                      const int32_t *slot2id, int32_t *slot, double *cls, int32_t *gexp, unsigned long long *dmax, int32_t *bad,
+                      hipStream_t s)
+{
+    if (nblocks == 0 || nid == 0) return;
+    const unsigned g1 = (unsigned)((nid * bs * bs + kThreads - 1) / kThreads), g2 = (unsigned)((nblocks + kThreads - 1) / kThreads);
+    if (bs == 2) {
+        hipLaunchKernelGGL((dict_cls_base_kernel<2>), dim3(g1), dim3(kThreads), 0, s, v0, v1, ldp, rep_of_id, nid, cls);
+        hipLaunchKernelGGL((dict_cls_stats_kernel<2>), dim3(g2), dim3(kThreads), 0, s, v0, v1, ldp, nblocks, slot2id, slot, cls, gexp, dmax, bad);
+    } else {
+        hipLaunchKernelGGL((dict_cls_base_kernel<3>), dim3(g1), dim3(kThreads), 0, s, v0, v1, ldp, rep_of_id, nid, cls);
+        hipLaunchKernelGGL((dict_cls_stats_kernel<3>), dim3(g2), dim3(kThreads), 0, s, v0, v1, ldp, nblocks, slot2id, slot, cls, gexp, dmax, bad);
+    }
+}
+
+// block rows: key = (length, then per block its column offset from the block row and its class)
+__global__ __launch_bounds__(kThreads) void dict_hash_rows_kernel(const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
+                                                                  const int32_t *__restrict__ blkid, int32_t nbrows,
+                                                                  unsigned long long *keys, int32_t *rep, int32_t *slot, int32_t *ctl,
+                                                                  int maxkeys, int kmax)
+{
+    const int br = blockIdx.x * kThreads + threadIdx.x;
+    if (br >= nbrows) return;
+    const int q0 = browptr[br], q1 = browptr[br + 1];
+    if (q1 - q0 > kmax) {   // a row longer than a row type may be: no such layout
+        __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot[br] = -1;
+        return;
+    }
+    unsigned long long h = mix64(0x13198A2E03707344ull, (unsigned long long)(q1 - q0));
+    for (int q = q0; q < q1; ++q)
+        h = mix64(h, ((unsigned long long)(uint32_t)(bcol[q] - br) << 32) | (unsigned long long)(uint32_t)blkid[q]);
+    slot[br] = dict_insert(h, br, keys, rep, ctl, maxkeys);
+}
+void dict_hash_rows(const int32_t *browptr, const int32_t *bcol, const int32_t *blkid, int32_t nbrows, unsigned long long *keys,
+                    int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys, int kmax, hipStream_t s)
+{
+    if (nbrows == 0) return;
+    hipLaunchKernelGGL(dict_hash_rows_kernel, dim3((nbrows + kThreads - 1) / kThreads), dim3(kThreads), 0, s, browptr, bcol, blkid,
+                       nbrows, keys, rep, slot, ctl, maxkeys, kmax);
+}
+
+// tab = [ntype lengths (padded to an even count)] [ntype x kmax x {offset, class}]
+__global__ __launch_bounds__(kThreads) void dict_row_table_kernel(const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
+                                                                  const int32_t *__restrict__ blkid, const int32_t *__restrict__ rep_of_id,
+                                                                  int nid, int kmax, int32_t *__restrict__ tab)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= nid * kmax) return;
+    const int id = i / kmax, k = i % kmax;
+    const int br = rep_of_id[id];
+    const int q0 = browptr[br], len = browptr[br + 1] - q0;
+    if (k == 0) tab[id] = len;
+    int32_t *ent = tab + ((nid + 1) & ~1) + 2 * (size_t)i;
+    ent[0] = k < len ? bcol[q0 + k] - br : 0;
+    ent[1] = k < len ? blkid[q0 + k] : 0;
+}
+__global__ __launch_bounds__(kThreads) void dict_row_verify_kernel(const int32_t *__restrict__ browptr, const int32_t *__restrict__ bcol,
+                                                                   const int32_t *__restrict__ blkid, int32_t nbrows, int nid, int kmax,
+                                                                   const int32_t *__restrict__ slot2id, const int32_t *__restrict__ slot,
+                                                                   const int32_t *__restrict__ tab, uint16_t *__restrict__ tid,
+                                                                   int32_t *__restrict__ bad)
+{
+    const int br = blockIdx.x * kThreads + threadIdx.x;
+    if (br >= nbrows) return;
+    const int sl = slot[br];
+    const int id = sl >= 0 ? slot2id[sl] : -1;
+    bool same = id >= 0;
+    if (same) {
+        const int q0 = browptr[br], len = browptr[br + 1] - q0;
+        same = len == tab[id];
+        const int32_t *ent = tab + ((nid + 1) & ~1) + 2 * (size_t)id * kmax;
+        for (int k = 0; same && k < len; ++k) same = ent[2 * k] == bcol[q0 + k] - br && ent[2 * k + 1] == blkid[q0 + k];
+    }
+    if (!same) *bad = 1;
+    tid[br] = (uint16_t)(same ? id : 0);
+}
+void dict_fill_rows(const int32_t *browptr, const int32_t *bcol, const int32_t *blkid, int32_t nbrows, const int32_t *rep_of_id,
+                    int nid, int kmax, const int32_t *slot2id, const int32_t *slot, int32_t *tab, uint16_t *tid, int32_t *bad,
+                    hipStream_t s)
+{
+    if (nbrows == 0 || nid == 0) return;
+    hipLaunchKernelGGL(dict_row_table_kernel, dim3((nid * kmax + kThreads - 1) / kThreads), dim3(kThreads), 0, s, browptr, bcol, blkid,
+                       rep_of_id, nid, kmax, tab);
+    hipLaunchKernelGGL(dict_row_verify_kernel, dim3((nbrows + kThreads - 1) / kThreads), dim3(kThreads), 0, s, browptr, bcol, blkid,
+                       nbrows, nid, kmax, slot2id, slot, tab, tid, bad);
+}
+
+// codes: k = (value - base) / 2^g into the plane of the block's position; then every value decoded as the product
+// kernels decode it and compared bit by bit (*bad)
+template <int BS>
+__global__ __launch_bounds__(kThreads) void dict_encode_kernel(DictArgs d, const int32_t *__restrict__ browptr,
+                                                               const int32_t *__restrict__ blkid, const double *__restrict__ v0,
+                                                               const double *__restrict__ v1, int64_t ldp, unsigned char *__restrict__ codes,
+                                                               int32_t *__restrict__ bad)
+{
+    const int64_t br = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (br >= d.nbrows) return;
+    const int q0 = browptr[br], len = browptr[br + 1] - q0;
+    for (int k = 0; k < len; ++k) {
+        const int id = blkid[q0 + k];
+        const bool wide = (d.wide_mask >> k) & 1u;
+        int16_t *plo = reinterpret_cast<int16_t *>(codes + d.plane_off[k] + (size_t)dict_block_bytes(BS) * br);
+        int16_t *phi = plo + (size_t)(dict_block_bytes(BS) / 2) * d.nbrows_pad;
+#pragma unroll
+        for (int r = 0; r < BS; ++r)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                const int e = r * BS + j;
+                const double base = d.cls[2 * (id * BS * BS + e)], sc = d.cls[2 * (id * BS * BS + e) + 1];
+                const double kq = (blk_val<BS>(v0, v1, ldp, q0 + k, r, j) - base) / sc;
+                const long long kk = (long long)rint(kq);
+                if ((double)kk != kq || kk < (wide ? -1000000000ll : -32767ll) || kk > (wide ? 1000000000ll : 32767ll)) *bad = 1;
+                const int pos = BS == 2 ? e : 4 * r + j;   // bs = 3: three rows of three codes, padded to four
+                const int32_t k32 = (int32_t)kk;
+                const int16_t lo = (int16_t)(k32 & 0xffff);
+                plo[pos] = lo;
+                if (wide) phi[pos] = (int16_t)((k32 - (int32_t)lo) >> 16);   // code = sext(lo) + (hi << 16)
+            }
+    }
+}
+template <int BS>
+__global__ __launch_bounds__(kThreads) void dict_verify_kernel(DictArgs d, const int32_t *__restrict__ browptr,
+                                                               const int32_t *__restrict__ bcol, const double *__restrict__ v0,
+                                                               const double *__restrict__ v1, int64_t ldp, int32_t *__restrict__ bad)
+{
+    const int64_t br = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (br >= d.nbrows) return;
+    const int t = d.tid[br];
+    const int q0 = browptr[br], len = browptr[br + 1] - q0;
+    const int32_t *ent = d.tab + ((d.ntype + 1) & ~1) + 2 * (size_t)t * d.kmax;
+    bool ok = t < d.ntype && d.tab[t] == len;
+    for (int k = 0; ok && k < len; ++k) {
+        int code[BS * BS];
+        DictRaw<BS> raw;
+        dict_issue<BS>(d, k, br, raw);
+        dict_unpack<BS>(raw, code);
+        ok = ok && bcol[q0 + k] == (int)br + ent[2 * k];
+        const double2 *cb = reinterpret_cast<const double2 *>(d.cls) + (size_t)ent[2 * k + 1] * (BS * BS);
+#pragma unroll
+        for (int r = 0; r < BS; ++r)
+#pragma unroll
+            for (int j = 0; j < BS; ++j)
+                ok = ok && __double_as_longlong(dict_decode(code[r * BS + j], cb[r * BS + j])) ==
+                               __double_as_longlong(blk_val<BS>(v0, v1, ldp, q0 + k, r, j));
+    }
+    if (!ok) *bad = 1;
+}
+void dict_encode_verify(const DictDev &A, const int32_t *browptr, const int32_t *bcol, const int32_t *blkid, const double *v0,
+                        const double *v1, int64_t ldp, int32_t *bad, hipStream_t s)
+{
+    if (A.nbrows == 0) return;
+    int grid = 0;
+    const DictArgs d = dict_args(A, &grid);
+    const unsigned g = (unsigned)((A.nbrows + kThreads - 1) / kThreads);
+    if (A.bs == 2) {
+        hipLaunchKernelGGL((dict_encode_kernel<2>), dim3(g), dim3(kThreads), 0, s, d, browptr, blkid, v0, v1, ldp, A.codes.p, bad);
+        hipLaunchKernelGGL((dict_verify_kernel<2>), dim3(g), dim3(kThreads), 0, s, d, browptr, bcol, v0, v1, ldp, bad);
+    } else {
+        hipLaunchKernelGGL((dict_encode_kernel<3>), dim3(g), dim3(kThreads), 0, s, d, browptr, blkid, v0, v1, ldp, A.codes.p, bad);
+        hipLaunchKernelGGL((dict_verify_kernel<3>), dim3(g), dim3(kThreads), 0, s, d, browptr, bcol, v0, v1, ldp, bad);
+    }
+}
+
+}  // namespace k
+}  // namespace spk

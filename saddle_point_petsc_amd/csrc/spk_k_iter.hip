@@ -703,8 +703,6 @@ __global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
     const int64_t n2 = p.nl / 2;
     const int64_t i2 = (int64_t)rho * p.chunk + threadIdx.x;
     const bool active = !scalar_wg && (int)threadIdx.x < p.chunk && i2 < n2;
-    const bool dbg = p.dbg && (int)blockIdx.x == p.dbg_wg && threadIdx.x == 0;
-    if (dbg) p.dbg[0] = wall_clock64();
 
     // ---- phase B loads first (they depend on nothing computed here)
     double2 wv, dv, pe[NP], t0v[G];
@@ -783,7 +781,6 @@ __global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
     double yv[NP];
 #pragma unroll
     for (int r = 0; r < NP; ++r) yv[r] = MP > 0 ? ys[r] : 0.0;
-    if (dbg) p.dbg[1] = wall_clock64();  // prologue done
 
     if (scalar_wg) {
         // ---- the scalar / reducing workgroup
@@ -867,7 +864,6 @@ __global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
             wv.y += ai[v] * tt[v].y;
         }
     }
-    if (dbg) p.dbg[2] = wall_clock64() + (unsigned long long)(wv.x == 1.2345e300);  // MAXPY arithmetic done (loads arrived)
     double nrm = 0.0;
     if (active) {
         double2 zz;
@@ -903,7 +899,6 @@ __global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
         publish(p.partials + (size_t)blockIdx.x * kPartialLd, tsum);
         if (!p.last) __hip_atomic_store(p.flags + (size_t)rho * 32, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (dbg) p.dbg[3] = wall_clock64();  // flag raised
     const int t0 = wgd.x, t1 = wgd.y;
     if (p.last || t0 >= t1) return;
 
@@ -953,13 +948,11 @@ __global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
             if (threadIdx.x == 0 && p.err) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        if (dbg) p.dbg[4] = wall_clock64();  // neighbours' flags seen
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (dbg) p.dbg[5] = wall_clock64();  // acquire done
     }
 #pragma unroll
     for (int j = 0; j < kTB; ++j) {
@@ -1014,7 +1007,6 @@ __global__ __launch_bounds__(kThreads) void iter_ba_kernel(IterBA p)
                 p.wnext[r0 + lr] = sr;
             }
             __syncthreads();  // prod is rewritten by the next tile
-            if (dbg) p.dbg[6 + j] = wall_clock64();  // tile done
         }
     }
 }

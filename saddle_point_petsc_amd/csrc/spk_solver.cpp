@@ -150,6 +150,179 @@ static void agree_or_fail(spk_ctx *c, const Error *mine, const char *step)
     if (mine) throw *mine;
 }
 
+// Row types + deviation codes over the blocked copy just built (DictDev, spk_internal.hpp): block classes, then row
+// types, proposed by hashing on the device; granule and range of every class entry; codes; every value decoded and compared
+// bit by bit.  Leaves Adict.ok = false (the blocked kernels stay) for matrices that do not fit.  brp: the block row
+// pointers on the host.
+static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
+{
+    DictDev &D = c->Adict;
+    D.ok = false;
+    D.tid.release(); D.tab.release(); D.cls.release(); D.codes.release();
+    const char *fmt = getenv("SPK_SPMV_FORMAT");
+    if (fmt && (!strcmp(fmt, "csr") || !strcmp(fmt, "bcsr"))) return;
+    static const bool verbose = getenv("SPK_DICT_VERBOSE") != nullptr;
+    auto refuse = [&](const char *why, long a = 0, long b = 0) {
+        D.tid.release(); D.tab.release(); D.cls.release(); D.codes.release();
+        if (verbose) fprintf(stderr, "[spk] row types + codes refused: %s (%ld, %ld)\n", why, a, b);
+    };
+    hipStream_t s = c->stream;
+    const int32_t nbr = bs == 2 ? c->Ab.nbrows : c->Ab3.nbrows;
+    const int64_t nb = bs == 2 ? c->Ab.nblocks : c->Ab3.nblocks;
+    const int32_t *browptr = bs == 2 ? c->Ab.browptr.p : c->Ab3.browptr.p, *bcol = bs == 2 ? c->Ab.bcol.p : c->Ab3.bcol.p;
+    const double *v0 = bs == 2 ? c->Ab.vtop.p : c->Ab3.v.p, *v1 = bs == 2 ? c->Ab.vbot.p : nullptr;
+    const int64_t ldp = bs == 2 ? 0 : c->Ab3.ldp;
+    const int bb = bs * bs;
+    if (nbr == 0 || nb == 0 || nb > INT32_MAX) return refuse("empty or too many blocks", nbr, (long)nb);
+    DevBuf<unsigned long long> keys, dmax;
+    DevBuf<int32_t> rep, slot, ctl, slot2id_d, rep_d, bad, gexp;
+    keys.alloc_raw(k::kDictSlots);
+    rep.alloc_raw(k::kDictSlots);
+    ctl.alloc_raw(4);
+    bad.alloc(4);
+    slot2id_d.alloc_raw(k::kDictSlots);
+    rep_d.alloc_raw(std::max(k::kDictMaxPat, k::kDictMaxBlk));
+    std::vector<unsigned long long> hk(k::kDictSlots);
+    std::vector<int32_t> hr(k::kDictSlots), s2i(k::kDictSlots), reps;
+    int32_t hctl[4];
+    // one round of "hash, read the table back, number the classes by their first member": returns the class count or -1
+    auto classes = [&]() -> int {
+        SPK_HIP(hipMemcpyAsync(hctl, ctl.p, sizeof hctl, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipMemcpyAsync(hk.data(), keys.p, sizeof(unsigned long long) * k::kDictSlots, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipMemcpyAsync(hr.data(), rep.p, sizeof(int32_t) * k::kDictSlots, hipMemcpyDeviceToHost, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        if (hctl[1]) return -1;
+        std::vector<std::pair<int32_t, int32_t>> used;   // (first member, slot)
+        for (int i = 0; i < k::kDictSlots; ++i)
+            if (hk[(size_t)i]) used.push_back({hr[(size_t)i], i});
+        std::sort(used.begin(), used.end());
+        std::fill(s2i.begin(), s2i.end(), -1);
+        reps.clear();
+        for (size_t i = 0; i < used.size(); ++i) {
+            s2i[(size_t)used[i].second] = (int32_t)i;
+            reps.push_back(used[i].first);
+        }
+        SPK_HIP(hipMemcpyAsync(slot2id_d.p, s2i.data(), sizeof(int32_t) * k::kDictSlots, hipMemcpyHostToDevice, s));
+        SPK_HIP(hipMemcpyAsync(rep_d.p, reps.data(), sizeof(int32_t) * reps.size(), hipMemcpyHostToDevice, s));
+        SPK_HIP(hipStreamSynchronize(s));
+        return (int)reps.size();
+    };
+    auto reset = [&]() {
+        SPK_HIP(hipMemsetAsync(keys.p, 0, sizeof(unsigned long long) * k::kDictSlots, s));
+        SPK_HIP(hipMemsetAsync(rep.p, 0x7f, sizeof(int32_t) * k::kDictSlots, s));
+        SPK_HIP(hipMemsetAsync(ctl.p, 0, sizeof(int32_t) * 4, s));
+    };
+    // ---- block classes: blocks equal up to ~1e-6 absolute; base = the first member; granule and range per entry
+    slot.alloc_raw((size_t)nb, 8);
+    reset();
+    k::dict_hash_blocks(bs, v0, v1, ldp, nb, keys.p, rep.p, slot.p, ctl.p, k::kDictMaxBlk, s);
+    const int ncls = classes();
+    if (ncls <= 0) return refuse("block classes beyond the table", hctl[0], hctl[1]);
+    D.cls.alloc_raw((size_t)ncls * bb * 2, 8);
+    gexp.alloc_raw((size_t)ncls * bb, 8);
+    dmax.alloc((size_t)ncls * bb, 8);
+    SPK_HIP(hipMemsetAsync(gexp.p, 0x7f, sizeof(int32_t) * (size_t)ncls * bb, s));
+    k::dict_class_stats(bs, v0, v1, ldp, nb, rep_d.p, ncls, slot2id_d.p, slot.p, D.cls.p, gexp.p, dmax.p, bad.p, s);   // slot[q] := class
+    std::vector<int32_t> hg((size_t)ncls * bb);
+    std::vector<unsigned long long> hm((size_t)ncls * bb);
+    std::vector<double> hcls((size_t)ncls * bb * 2);
+    int32_t hbad = 1;
+    SPK_HIP(hipMemcpyAsync(hg.data(), gexp.p, sizeof(int32_t) * hg.size(), hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipMemcpyAsync(hm.data(), dmax.p, sizeof(unsigned long long) * hm.size(), hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipMemcpyAsync(hcls.data(), D.cls.p, sizeof(double) * hcls.size(), hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipStreamSynchronize(s));
+    if (hbad) return refuse("a deviation from its class base is not exactly representable");
+    std::vector<char> cls_wide((size_t)ncls, 0);
+    for (int i = 0; i < ncls * bb; ++i) {
+        double scale = 1.0;
+        if (hg[(size_t)i] < 0x7f000000) {   // some member deviates: granule = the finest bit in use
+            if (hg[(size_t)i] < -1000 || hg[(size_t)i] > 1000) return refuse("deviation granule out of range", i, hg[(size_t)i]);
+            scale = std::ldexp(1.0, hg[(size_t)i]);
+            double mag;
+            std::memcpy(&mag, &hm[(size_t)i], sizeof mag);
+            const double kabs = mag / scale;
+            if (!(kabs <= 1.0e9)) return refuse("a class scatters beyond 32-bit codes", i, (long)hg[(size_t)i]);
+            if (kabs > 32767.0) cls_wide[(size_t)(i / bb)] = 1;
+        }
+        hcls[(size_t)2 * i + 1] = scale;
+    }
+    SPK_HIP(hipMemcpyAsync(D.cls.p, hcls.data(), sizeof(double) * hcls.size(), hipMemcpyHostToDevice, s));
+    // ---- row types
+    DevBuf<int32_t> rslot;
+    rslot.alloc_raw((size_t)nbr, 8);
+    reset();
+    k::dict_hash_rows(browptr, bcol, slot.p, nbr, keys.p, rep.p, rslot.p, ctl.p, k::kDictMaxPat, kDictMaxK, s);
+    const int ntype = classes();
+    if (ntype <= 0) return refuse("row types beyond the table, or a row beyond kDictMaxK blocks", hctl[0], hctl[1]);
+    int kmax = 1;
+    for (int32_t r : reps) kmax = std::max(kmax, brp[(size_t)r + 1] - brp[(size_t)r]);
+    const int tab_ints = ((ntype + 1) & ~1) + 2 * ntype * kmax;
+    const int lds_bytes = ((4 * tab_ints + 15) & ~15) + 16 * ncls * bb;
+    if (lds_bytes > k::kDictLdsMax) return refuse("tables beyond the LDS budget", lds_bytes, ntype);
+    D.tab.alloc((size_t)tab_ints, 8);
+    D.tid.alloc_raw((size_t)nbr, 64);
+    k::dict_fill_rows(browptr, bcol, slot.p, nbr, rep_d.p, ntype, kmax, slot2id_d.p, rslot.p, D.tab.p, D.tid.p, bad.p, s);
+    std::vector<int32_t> htab((size_t)tab_ints);
+    SPK_HIP(hipMemcpyAsync(htab.data(), D.tab.p, sizeof(int32_t) * htab.size(), hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipStreamSynchronize(s));
+    if (hbad) return refuse("row type verification failed (hash collision)", ntype, ncls);
+    // ---- code planes: position k of every block row; 32-bit codes where any type puts a wide class there
+    D.wide_mask = 0;
+    std::vector<int64_t> rows_at((size_t)kmax, 0);   // (for the byte model: rows that have a block at position k -- all, up to the few short types)
+    for (int t = 0; t < ntype; ++t)
+        for (int kk = 0; kk < htab[(size_t)t]; ++kk)
+            if (cls_wide[(size_t)htab[(size_t)(((ntype + 1) & ~1) + 2 * (t * kmax + kk) + 1)]]) D.wide_mask |= 1u << kk;
+    int64_t off = 0;
+    for (int kk = 0; kk < kDictMaxK; ++kk) {
+        D.plane_off[kk] = off;
+        // (a wide position: the plane of low halves, then the plane of high halves)
+        if (kk < kmax) off += (int64_t)(bs == 2 ? 8 : 24) * (((D.wide_mask >> kk) & 1u) ? 2 : 1) * (((int64_t)nbr + 15) & ~(int64_t)15);
+    }
+    D.codes.alloc((size_t)off, 64);
+    D.bs = bs;
+    D.nbrows = nbr;
+    D.nblocks = nb;
+    D.ntype = ntype;
+    D.nclass = ncls;
+    D.kmax = kmax;
+    D.lds_bytes = lds_bytes;
+    // bytes of codes one product reads: every stored block once, at its position's width
+    {
+        std::vector<int64_t> len_count((size_t)kmax + 1, 0);
+        // (block rows by length from the host's row pointers)
+        for (int32_t br = 0; br < nbr; ++br) len_count[(size_t)std::min(kmax, brp[(size_t)br + 1] - brp[(size_t)br])]++;
+        int64_t rows_ge = 0, bytes = 0;
+        for (int kk = kmax - 1; kk >= 0; --kk) {
+            rows_ge += len_count[(size_t)kk + 1];
+            bytes += rows_ge * (bs == 2 ? 8 : 24) * (((D.wide_mask >> kk) & 1u) ? 2 : 1);
+        }
+        D.code_bytes = bytes;
+    }
+    k::dict_encode_verify(D, browptr, bcol, slot.p, v0, v1, ldp, bad.p, s);
+    SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipStreamSynchronize(s));
+    if (hbad) return refuse("a decoded value differs from the stored one", ntype, ncls);
+    D.ok = true;
+    if (verbose) {
+        int nw = 0;
+        for (int kk = 0; kk < kmax; ++kk) nw += (D.wide_mask >> kk) & 1u;
+        fprintf(stderr, "[spk] row types + codes: %d block rows, %d types (<= %d blocks, %d positions with 32-bit codes), %d classes of %d x %d, "
+                        "%d B of LDS, %.1f B of codes per block row\n", nbr, ntype, kmax, nw, ncls, bs, bs, lds_bytes, (double)D.code_bytes / nbr);
+    }
+}
+
+void a_mult(spk_ctx *c, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done, bool accumulate,
+            const k::OffDiag *od, const k::GivensRider *rider)
+{
+    hipStream_t s = c->stream;
+    if (c->spmv_format != 0 && c->Adict.ok) k::spmv_dict(c->Adict, x, y, bt, lam, done, s, accumulate, od, rider);
+    else if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, x, y, bt, lam, done, s, accumulate, od, rider);
+    else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, bt, lam, done, s, accumulate, od, rider);
+    else k::spmv(c->Ad, x, y, bt, lam, done, s, accumulate, od, rider);
+}
+
 static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
                         const int32_t *rowptr, const int32_t *colidx, const double *val)
 {
@@ -274,6 +447,7 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
     // and filled by one kernel, block row br starting at block rowptr[2 br] / 4
     {
         BcsrDev &Ab = c->Ab;
+        c->Adict.ok = false;
         Ab.ok = false;
         Ab.nbrows = 0;
         Ab.ntiles = 0;
@@ -312,6 +486,7 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
                     Ab.tile_desc.upload(td.data(), td.size(), 8);
                 }
                 Ab.ok = true;
+                build_dict(c, 2, brp.data());
                 // BA iteration kernel: workgroup rho (row order) owns ba_tb consecutive tiles of its XCD's range; it
                 // may start its SpMV phase once the owners of the rows its block columns touch have stored their z~
                 Ab.ba_ok = false;
@@ -412,6 +587,7 @@ static void set_block_A(spk_ctx *c, int64_t row_begin, int32_t nrows_local, int6
                 A3.ntiles = (int32_t)tb.size() - 1;
                 A3.tile_brow.upload(tb.data(), tb.size(), 8);
                 A3.ok = true;
+                build_dict(c, 3, brp.data());
             } else {
                 A3.browptr.release(); A3.bcol.release(); A3.v.release();
             }
@@ -520,17 +696,20 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
     col.alloc((size_t)rowptr[m]);
     v.alloc((size_t)rowptr[m]);
     {
-        std::vector<int32_t> badcol(64, -1);
+        // a flag of its own per thread: any int32 -- -1 included -- can be the offending column number
+        std::vector<char> bad(64, 0);
+        std::vector<int32_t> badcol(64, 0);
         parallel_for(rowptr[m], [&](int64_t a, int64_t b, int t) {
             for (int64_t k = a; k < b; ++k) {
                 const int32_t g = colidx[k];
-                if (g < lo || g >= hi) badcol[(size_t)t] = g;
+                if (g < lo || g >= hi) bad[(size_t)t] = 1, badcol[(size_t)t] = g;
                 col[(size_t)k] = (int32_t)(g - lo);
                 v[(size_t)k] = val[k];
             }
         });
-        for (int32_t g : badcol)
-            if (g != -1) fail(SPK_ERR_ARG, "A10: column %d not owned by this rank [%lld,%lld)", g, (long long)lo, (long long)hi);
+        for (size_t t = 0; t < bad.size(); ++t)
+            if (bad[t])
+                fail(SPK_ERR_ARG, "A10: column %d not owned by this rank [%lld,%lld)", badcol[t], (long long)lo, (long long)hi);
         for (int32_t r = 0; r < m; ++r) {   // PETSc rows come sorted: nothing to do then
             const int32_t k0 = rowptr[r], k1 = rowptr[r + 1];
             if (std::is_sorted(col.data() + k0, col.data() + k1)) continue;
@@ -728,9 +907,7 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool h
     }
     const k::OffDiag od = c->offdiag();
     const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;   // off-rank columns in the same kernel
-    if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
-    else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
-    else k::spmv(c->Ad, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, s, false, odp);
+    a_mult(c, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, false, odp);
     if (m > 0) {
         apply_B(c, x, nullptr, y + nl, done);
         c->comm->allreduce_sum(y + nl, m, s);
@@ -800,13 +977,14 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     c->Ab3.v32.release();
     c->Ab.vtop32.release();
     c->Ab.vbot32.release();
-    if (c->inner_sweeps > 0 && c->spmv_format == 1) {   // ... or the 2x2-blocked value planes
+    const bool dict = c->spmv_format != 0 && c->Adict.ok;   // (the sweeps then decode the codes and round to single precision)
+    if (c->inner_sweeps > 0 && !dict && c->spmv_format == 1) {   // ... or the 2x2-blocked value planes
         c->Ab.vtop32.alloc_raw((size_t)(2 * c->Ab.nblocks + 8), 32);
         c->Ab.vbot32.alloc_raw((size_t)(2 * c->Ab.nblocks + 8), 32);
         k::cvt_vals_f32(c->Ab.vtop.p, c->Ab.vtop32.p, 2 * c->Ab.nblocks, s);
         k::cvt_vals_f32(c->Ab.vbot.p, c->Ab.vbot32.p, 2 * c->Ab.nblocks, s);
     }
-    if (c->inner_sweeps > 0 && c->spmv_format == 2) {   // the sweeps read the 3x3-blocked planes in single precision
+    if (c->inner_sweeps > 0 && !dict && c->spmv_format == 2) {   // the sweeps read the 3x3-blocked planes in single precision
         c->Ab3.v32.alloc_raw((size_t)(9 * c->Ab3.ldp), 32);
         k::cvt_vals_f32(c->Ab3.v.p, c->Ab3.v32.p, 9 * c->Ab3.ldp, s);
     }
@@ -864,7 +1042,8 @@ static void inner_apply(spk_ctx *c, const double *x, double *y, int mode, const 
             k::gather_f32(ya, c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
             c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
         }
-        if (c->spmv_format == 2) k::jacobi_sweep_f32_b3(c->Ab3, c->d32.p, om, c->x32.p, ya, yb, done, s);
+        if (c->spmv_format != 0 && c->Adict.ok) k::jacobi_sweep_f32_dict(c->Adict, c->d32.p, om, c->x32.p, ya, yb, done, s);
+        else if (c->spmv_format == 2) k::jacobi_sweep_f32_b3(c->Ab3, c->d32.p, om, c->x32.p, ya, yb, done, s);
         else if (c->spmv_format == 1) k::jacobi_sweep_f32_b2(c->Ab, c->d32.p, om, c->x32.p, ya, yb, done, s);
         else k::jacobi_sweep_f32(c->Ad, c->a32.p, c->d32.p, om, c->x32.p, ya, yb, done, s);
         if (c->n_ghost > 0) k::sweep_offdiag_f32(c->Ao, c->ao_rows.p, c->d32.p, om, c->xghost.p, yb, done, s);
@@ -1049,14 +1228,21 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // How one classical Gram-Schmidt iteration (two reductions) is launched on the head-kernel paths
     // (opts.iteration_form / SPK_ITER_FORM; include/spk.h lists the forms and their measured times).
     int form = o.iteration_form;
-    if (const char *e = getenv("SPK_ITER_FORM")) form = atoi(e);
+    if (const char *e = getenv("SPK_ITER_FORM")) {   // test-only knob: the whole GPU suite is run under each form with it
+        char *end = nullptr;
+        const long f = strtol(e, &end, 10);
+        if (end == e || *end || f < SPK_ITER_AUTO || f > SPK_ITER_LAST)
+            fail(SPK_ERR_ARG, "SPK_ITER_FORM=%s: not an iteration form (%d..%d)", e, (int)SPK_ITER_AUTO, (int)SPK_ITER_LAST);
+        form = (int)f;
+    }
+    if (form < SPK_ITER_AUTO || form > SPK_ITER_LAST) fail(SPK_ERR_ARG, "fgmres: unknown iteration_form %d", form);
     // AUTO: three launches on an UN-normalised basis -- MDot (raw inner products), MAXPY + norm + next PCApply, plain SpMV
     // with the Givens step and the new scale factor in one extra workgroup (GivensRider).  V~_j = h_{j,j-1} v_j: nothing
     // compounds, no vector is ever scaled in memory.  Either matrix format, any number of ranks, any transport.
     const bool un3 = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                      mk + c->m <= k::kMaxNv - 2 && (form == SPK_ITER_UNNORM || form == SPK_ITER_AUTO);
     const bool two_ok = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
-                        c->spmv_format == 1 && !c->Ab.long_rows && mk + c->m <= k::kMaxNv - 2;
+                        c->spmv_format == 1 && c->Ab.ok && !c->Ab.long_rows && mk + c->m <= k::kMaxNv - 2;
     const bool two = two_ok && !un3 && (form == SPK_ITER_TWO_LAUNCH || form == SPK_ITER_THREE_LAUNCH);
     // forms 2 / 3 (normalised basis, MDot inside / behind the SpMV launch): opt-in, kept for comparison
     const bool three = two && form != SPK_ITER_TWO_LAUNCH;
@@ -1076,6 +1262,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     }
     if (two && c->zun.n < (size_t)ld) c->zun.alloc((size_t)ld);
     const int lam_in_dot = c->comm->rank() == 0 ? 1 : 0;
+    c->last_form = ba ? SPK_ITER_BA : un3 ? SPK_ITER_UNNORM : two ? (three ? SPK_ITER_THREE_LAUNCH : SPK_ITER_TWO_LAUNCH)
+                   : head ? SPK_ITER_FOUR_LAUNCH : -1;
+    c->last_single = single ? 1 : 0;
 
     c->ka.tentative = single ? 1 : 0;
     KrylovState st{};
@@ -1153,9 +1342,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     }
                     const k::OffDiag od = c->offdiag();
                     const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;
-                    if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
-                    else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
-                    else k::spmv(c->Ad, zvec, wvec, nullptr, nullptr, done, s, fused, odp, rider);
+                    a_mult(c, zvec, wvec, nullptr, nullptr, done, fused, odp, rider);
                 };
                 if (loc == 0) {
                     // first iteration of a cycle: the classic head on the normalised r, then the plain product
@@ -1228,24 +1415,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 p.partials = c->partials.p; p.nrm_out = nb;
                 p.err = c->errw.p; p.fin_ticks = c->fin_ticks;
                 p.ka = c->ka; p.loc = loc; p.done = done;
-                static const char *dbgenv = getenv("SPK_BA_DEBUG");
-                static DevBuf<unsigned long long> &dbgbuf = *new DevBuf<unsigned long long>();  // (never freed: no hipFree at exit)
-                const bool dbgnow = dbgenv && loc == 20 && cycles == 1;
-                if (dbgnow) {
-                    if (!dbgbuf.p) dbgbuf.alloc(16);
-                    p.dbg = dbgbuf.p;
-                    p.dbg_wg = atoi(dbgenv);
-                }
                 k::iter_ba(p, s);
                 last = -1;  // the Givens step of this iteration ran inside the launch
-                if (dbgnow) {
-                    unsigned long long h[16];
-                    SPK_HIP(hipStreamSynchronize(s));
-                    SPK_HIP(hipMemcpy(h, dbgbuf.p, sizeof h, hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[BA wg %d, loc %d] prologue %.2f  maxpy %.2f  flag %.2f  waited %.2f  acquire %.2f  tiles %.2f %.2f %.2f %.2f us (from entry)\n",
-                            p.dbg_wg, loc, (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0, (h[4] - h[0]) / 100.0,
-                            (h[5] - h[0]) / 100.0, (h[6] - h[0]) / 100.0, (h[7] - h[0]) / 100.0, (h[8] - h[0]) / 100.0, (h[9] - h[0]) / 100.0);
-                }
                 }
             } else if (two) {
                 k::SendRanges sr0 = c->send_ranges;
@@ -1339,9 +1510,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     if (!packed) k::gather(Zj(loc), c->send_idx.p, c->send_off.back(), c->send_buf.p, done, s);
                     c->comm->exchange(c->send_buf.p, c->peers, c->send_off, c->xghost.p, c->recv_off, s);
                 }
-                if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
-                else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
-                else k::spmv(c->Ad, Zj(loc), w, nullptr, nullptr, done, s, true, c->n_ghost > 0 ? &od : nullptr);
+                a_mult(c, Zj(loc), w, nullptr, nullptr, done, true, c->n_ghost > 0 ? &od : nullptr);
             } else if (fusedj) {
                 bool inhead = prev_inhead;
                 if (!head_done) {

@@ -179,7 +179,19 @@ class Context:
     def spmv_info(self):
         fmt, b = C.c_int32(), C.c_int64()
         lib.spk_get_spmv_info(self.h, C.byref(fmt), C.byref(b))
-        return dict(format={0: "csr", 1: "bcsr2x2", 2: "bcsr3x3"}[fmt.value], layout_bytes=b.value)
+        return dict(format={0: "csr", 1: "bcsr2x2", 2: "bcsr3x3", 3: "dict2x2", 4: "dict3x3"}[fmt.value], layout_bytes=b.value)
+
+    def iteration_form(self):
+        """(form, single_reduce) of the last fgmres on this context: the SPK_ITER_* actually run, -1 = step-by-step path."""
+        f, sr = C.c_int32(), C.c_int32()
+        self._chk(lib.spk_get_iteration_form(self.h, C.byref(f), C.byref(sr)))
+        return f.value, sr.value
+
+    def spmv_models(self):
+        """Bytes of one product y = A x in the CSR, blocked and row-pattern-dictionary layouts (0: layout absent)."""
+        a, b, d, p, q = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        self._chk(lib.spk_get_spmv_models(self.h, C.byref(a), C.byref(b), C.byref(d), C.byref(p), C.byref(q)))
+        return dict(csr_bytes=a.value, blocked_bytes=b.value, dict_bytes=d.value, patterns=p.value, blocks=q.value)
 
     def _n(self):
         s = self.sizes()

@@ -1017,7 +1017,7 @@ def test_3d_grid_config5_shape(spk, oracle):
     rhs = np.concatenate([f, g])
     with spk.Context(0) as c:
         c.set_block(spk.BLOCK_A00, A)
-        assert c.spmv_info()["format"] == "bcsr3x3"
+        assert c.spmv_info()["format"] == "dict3x3"    # (row types + codes over the 3 x 3 blocks; tests/test_gpu_dict.py)
         assert c.spmv_info()["layout_bytes"] < 0.75 * (12 * A.nnz + 4 * (A.nrows + 1) + 16 * A.nrows)
         assert np.array_equal(c.mult(x), oracle.spmv(Ao, x))                      # bitwise
         c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.8)
