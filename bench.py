@@ -133,8 +133,9 @@ def main():
     ap.add_argument("--inner-sweeps", type=int, default=0, help="FP32 damped-Jacobi Richardson sweeps standing for "
                                                                 "diag(A)^-1 in the PC (BASELINE config 5's mixed FP32 inner solve)")
     ap.add_argument("--inner-omega", type=float, default=0.8)
-    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
-                    help="opts.iteration_form: 0 auto, 1 four launches per iteration, 2 two launches, 3 three launches")
+    ap.add_argument("--iter-form", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
+                    help="opts.iteration_form: 0 auto, 1 four launches per iteration, 2 two launches, 3 three launches, 4 BA, "
+                         "5 un-normalised three-launch, 6 resident restart-cycle kernel")
     ap.add_argument("--single-reduce", type=int, default=0, help="1: single-reduction Gram-Schmidt (one all-reduce per iteration; see include/spk.h)")
     ap.add_argument("--watchdog", type=float, default=900.0, help="seconds after which a run that is still going says WHERE it "
                                                                   "is stuck (rank, phase) on stderr and exits 4; 0: off")
@@ -391,7 +392,7 @@ def main():
                                + (f"saddle K=[A B^T;B 0] with {B.nrows} constraint rows, " if saddle else "K=A, ")
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (B.nrows if saddle else 0), "dim": args.dim, "pc": args.pc, "restart": args.restart,
-                   "inner_fp32_sweeps": args.inner_sweeps, "iteration_form": args.iter_form,
+                   "inner_fp32_sweeps": args.inner_sweeps, "iteration_form": args.iter_form, "iteration_form_run": form_run,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
@@ -446,14 +447,24 @@ def main():
         mat_layout = spi["layout_bytes"] - 4 * (sz["n_local"] + 1) - 16 * sz["n_local"]
         itmodels = {}
         for name, steps_, secs in (("timed_steps", args.steps, elapsed), ("full_cycles", full_steps, elapsed_full)):
-            un = form_run == 5                  # the form the solver took (spk_get_iteration_form), not a guess from the options
+            un = form_run in (5, 6)             # the form the solver took (spk_get_iteration_form), not a guess from the options
             b_csr = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows, None, un)
             b_lay = solve_bytes(sz["n_local"], sz["nnz_local"], nnzB_local, args.restart, steps_, planes, mrows, mat_layout, un)
             itmodels[name] = {"steps": steps_, "bytes_per_iteration_csr_model": b_csr / steps_,
                             "bytes_per_iteration_layout": b_lay / steps_,
                             "achieved_gbps_csr_model": b_csr / secs / 1e9, "achieved_gbps_layout": b_lay / secs / 1e9,
                             "frac_of_peak": min(b_csr, b_lay) / secs / 1e9 / HBM_PEAK_GBS,
-                            "form": "unnormalised three-launch" if un else "head + SpMV + MDot + MAXPY"}
+                            "form": ("resident restart-cycle kernel (basis in registers): the figures are what the three-launch "
+                                     "form would stream -- this form moves ~3 vectors + the matrix codes per iteration and is bound by "
+                                     "its two grid-wide exchanges per iteration, not by bandwidth") if form_run == 6
+                                    else "unnormalised three-launch" if un else "head + SpMV + MDot + MAXPY"}
+            if form_run == 6:
+                vec = 8 * sz["n_local"]
+                moved = spi["layout_bytes"] - 16 * sz["n_local"] + 3 * vec    # codes + z~ stored, gathered; Z read at the cycle end
+                itmodels[name]["bytes_per_iteration_resident_form"] = moved
+                itmodels[name]["achieved_gbps_resident_form"] = moved * steps_ / secs / 1e9
+                itmodels[name]["frac_of_peak"] = moved * steps_ / secs / 1e9 / HBM_PEAK_GBS
+                itmodels[name]["bound"] = "latency: two grid-wide exchanges per iteration (inner products all-to-all, z~ hand-off)"
         out["iteration_model"] = itmodels
         out["value_representative_model"] = itmodels["full_cycles"]
     if not residual_ok:

@@ -126,12 +126,19 @@ typedef struct spk_opts {
                                SPK_ITER_BA (4, single rank, small systems): VecMAXPY + norm + next PCApply AND the next
                                MatMult in one launch behind neighbour flags, un-normalised basis (two launches per
                                iteration; measured no faster than 5: bandwidth-bound).
+                               SPK_ITER_RESIDENT (6; what AUTO takes on small single-rank systems: <= 512 block rows per
+                               compute unit, restart <= 30, the row-type matrix layout): ONE launch per restart cycle, one
+                               workgroup per CU, every thread keeps its entries of the un-normalised basis in registers --
+                               VecMDot is a register dot product + an all-to-all of the partial sums (every workgroup adds
+                               all of them in one order and runs the Hessenberg / Givens / convergence scalars itself),
+                               VecMAXPY touches no memory, the product gathers z~ from the neighbours' write-through
+                               stores.  Same algorithm and basis as 5.  SPK_RESIDENT=0 keeps AUTO on 5;
                                Measured us per iteration, forms 1 / 3 / 5: 1/8 slab of 1024^2 47.9 / 44.7 / 43.3,
                                512^2 71.8 / 67.6 / 66.0, 1024^2 219.7 / 218 / 209.2 (profiles/r02*). */
     int32_t reserved;
 } spk_opts;
 enum { SPK_ITER_AUTO = 0, SPK_ITER_FOUR_LAUNCH = 1, SPK_ITER_TWO_LAUNCH = 2, SPK_ITER_THREE_LAUNCH = 3, SPK_ITER_BA = 4,
-       SPK_ITER_UNNORM = 5, SPK_ITER_LAST = 5 };
+       SPK_ITER_UNNORM = 5, SPK_ITER_RESIDENT = 6, SPK_ITER_LAST = 6 };
 
 typedef struct spk_result {
     int32_t its;            /* KSPGetIterationNumber   */

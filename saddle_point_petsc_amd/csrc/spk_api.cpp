@@ -74,6 +74,7 @@ int spk_create(spk_ctx **out, int device)
         c->device = device;
         SPK_HIP(hipSetDevice(device));
         SPK_HIP(hipStreamCreate(&c->stream));
+        SPK_HIP(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         // the solver's state report (pinned block + event): here, not inside the first solve
         SPK_HIP(hipHostMalloc(&c->pin_state, 512, hipHostMallocDefault));
         SPK_HIP(hipEventCreateWithFlags(&c->state_ev, hipEventDisableTiming));

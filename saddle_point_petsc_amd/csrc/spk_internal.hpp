@@ -662,6 +662,25 @@ struct IterBA {
     const int32_t *done;
 };
 void iter_ba(const IterBA &p, hipStream_t s);
+// Resident restart cycle (spk_k_resident.hip): ONE launch runs iterations 0 .. mk-1 of a cycle with the basis in registers
+// (single rank, row-type layout with 2x2 blocks, <= 512 block rows per CU, restart <= 30, <= 4 planes of B D).  On entry
+// V0 = v_0 (normalised), V1 = K z_0; Z_1.. are written; the Krylov scalars end up where krylov_cycle_end expects them.
+struct ResidentArgs {
+    int mk, m, packed, fact, lam_in_dot;
+    int64_t nl, ld;
+    const double *V0, *V1;
+    double *Z;
+    const double *dinv, *bd;
+    int64_t ldb;
+    const double *shat, *gram;
+    double *P;             // resident_scratch_doubles() doubles
+    KrylovArrays ka;
+    double *sc_out;
+    int32_t *err;
+    uint32_t ticks;
+};
+bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t *done, hipStream_t s);   // false: shape does not fit
+int64_t resident_scratch_doubles(int num_cus, int mk);
 // block-column range of every tile of the blocked matrix (set-up of the BA kernel's neighbour lists)
 void tile_col_range(const int32_t *browptr, const int32_t *bcol, const int32_t *tile_brow, int ntiles, int32_t *out, hipStream_t s);
 int iter_maxpy_uhead(IterB b, hipStream_t s);   // returns the number of partial rows (GivensRider::fin_n)
@@ -777,6 +796,8 @@ struct spk_ctx {
     spk::DevBuf<double> zun;    // z~ of the two-launch iteration (un-normalised M^-1 w')
     spk::DevBuf<uint32_t> ba_flags;  // BA kernel: one 128-byte line per workgroup
     spk::DevBuf<double> ba_sc;       // scale factors of the un-normalised basis
+    spk::DevBuf<double> res_P;       // resident cycle kernel: all-to-all buffer of the inner products
+    int num_cus = 0;                 // compute units of the device (grid of the resident cycle kernel)
     uint32_t ba_seq = 0;
     spk::DevBuf<double> kry_d;  // H, cc, ss, rs, nrs, hcol, hist
     spk::DevBuf<spk::KrylovState> kst;

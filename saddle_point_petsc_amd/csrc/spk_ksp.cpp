@@ -236,7 +236,7 @@ int SpkKSPSetFromOptions(SpkKSP k, int argc, const char *const *argv)
         } else if (key == "-spk_single_reduce") {
             if (!val || !parse_int(val, &k->opts.single_reduce)) return need("an integer (0 off, 1 on)");
         } else if (key == "-spk_iteration_form") {
-            if (!val || !parse_int(val, &k->opts.iteration_form) || k->opts.iteration_form < 0 || k->opts.iteration_form > 5)
+            if (!val || !parse_int(val, &k->opts.iteration_form) || k->opts.iteration_form < 0 || k->opts.iteration_form > SPK_ITER_LAST)
                 return need("an integer 0..5 (0 automatic, 1 four / 2 two / 3 three launches per iteration, 4 BA, 5 three launches on an un-normalised basis)");
         } else if (key == "-spk_check_every") {
             if (!val || !parse_int(val, &k->opts.check_every)) return need("an integer");

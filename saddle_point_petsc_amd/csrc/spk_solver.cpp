@@ -1240,7 +1240,18 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // with the Givens step and the new scale factor in one extra workgroup (GivensRider).  V~_j = h_{j,j-1} v_j: nothing
     // compounds, no vector is ever scaled in memory.  Either matrix format, any number of ranks, any transport.
     const bool un3 = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
-                     mk + c->m <= k::kMaxNv - 2 && (form == SPK_ITER_UNNORM || form == SPK_ITER_AUTO);
+                     mk + c->m <= k::kMaxNv - 2 && (form == SPK_ITER_UNNORM || form == SPK_ITER_AUTO || form == SPK_ITER_RESIDENT);
+    // RESIDENT: one launch per restart cycle, the basis in registers (spk_k_resident.hip): what AUTO takes where it fits
+    static const bool res_env_off = [] { const char *e = getenv("SPK_RESIDENT"); return e && !strcmp(e, "0"); }();
+    const int res_planes = !fused ? 0 : (bpk ? m / 2 : m);
+    const bool resident = un3 && (form == SPK_ITER_RESIDENT || (form == SPK_ITER_AUTO && !res_env_off)) && c->comm->size() == 1 &&
+                          c->peers.empty() && c->n_ghost == 0 && c->spmv_format == 1 && c->Adict.ok && c->Adict.bs == 2 &&
+                          nl % 2 == 0 && mk <= 30 && mk >= 2 && res_planes <= 4 && c->num_cus > 0 &&
+                          (int64_t)c->Adict.nbrows <= (int64_t)c->num_cus * 512;
+    if (resident) {
+        const size_t need = (size_t)k::resident_scratch_doubles(c->num_cus, mk);
+        if (c->res_P.n < need) c->res_P.alloc(need);
+    }
     const bool two_ok = head && !single && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine == SPK_REFINE_NEVER &&
                         c->spmv_format == 1 && c->Ab.ok && !c->Ab.long_rows && mk + c->m <= k::kMaxNv - 2;
     const bool two = two_ok && !un3 && (form == SPK_ITER_TWO_LAUNCH || form == SPK_ITER_THREE_LAUNCH);
@@ -1262,7 +1273,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     }
     if (two && c->zun.n < (size_t)ld) c->zun.alloc((size_t)ld);
     const int lam_in_dot = c->comm->rank() == 0 ? 1 : 0;
-    c->last_form = ba ? SPK_ITER_BA : un3 ? SPK_ITER_UNNORM : two ? (three ? SPK_ITER_THREE_LAUNCH : SPK_ITER_TWO_LAUNCH)
+    c->last_form = resident ? SPK_ITER_RESIDENT : ba ? SPK_ITER_BA : un3 ? SPK_ITER_UNNORM : two ? (three ? SPK_ITER_THREE_LAUNCH : SPK_ITER_TWO_LAUNCH)
                    : head ? SPK_ITER_FOUR_LAUNCH : -1;
     c->last_single = single ? 1 : 0;
 
@@ -1356,6 +1367,17 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                         k::fused_head(Vj(0), nrmbuf(1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER, nl, 0,
                                       Zj(0), nullptr, c->ka, -1, dotsbuf(1), done, s, packed ? &sr0 : nullptr);
                     product(Zj(0), w, inhead);
+                }
+                if (resident) {
+                    // the rest of the cycle is ONE launch: iterations 0 .. mk-1 with the basis in registers
+                    k::ResidentArgs r{};
+                    r.mk = mk; r.m = fused ? m : 0; r.packed = bpk; r.fact = fused ? c->schur_fact : SPK_SCHUR_LOWER;
+                    r.lam_in_dot = lam_in_dot; r.nl = nl; r.ld = ld;
+                    r.V0 = Vj(0); r.V1 = Vj(1); r.Z = Z; r.dinv = c->dinv.p; r.bd = bdp; r.ldb = ld;
+                    r.shat = c->shat.p; r.gram = c->gram.p; r.P = c->res_P.p; r.ka = c->ka; r.sc_out = c->ba_sc.p;
+                    r.err = c->errw.p; r.ticks = c->fin_ticks;
+                    if (!k::cycle_resident(c->Adict, c->num_cus, r, done, s)) fail(SPK_ERR_STATE, "fgmres: resident cycle kernel refused its shape");
+                    break;
                 }
                 // raw inner products of the un-normalised basis with w~ (and B D w~); scaled where they are consumed
                 {

@@ -282,12 +282,13 @@ def test_converged_default_reference_norm_on_device(spk, oracle):
 
 
 # --------------------------------------------------------------------------- iteration forms
-@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("pc", ["jacobi", "schur"])
 def test_every_iteration_form_against_the_oracle(spk, oracle, form, pc):
-    """opts.iteration_form 1..5 (include/spk.h) are re-schedulings of the same classical Gram-Schmidt FGMRES:
-    every one of them must reproduce the oracle's residual history and solution (AUTO picks form 5 where it
-    applies, so the rest of the suite covers that one; a form that does not apply to a set-up falls back)."""
+    """opts.iteration_form 1..6 (include/spk.h) are re-schedulings of the same classical Gram-Schmidt FGMRES:
+    every one of them must reproduce the oracle's residual history and solution (AUTO picks form 6 -- the resident
+    restart-cycle kernel -- on small single-rank systems and form 5 elsewhere, so the rest of the suite covers those;
+    a form that does not apply to a set-up falls back)."""
     M = 48
     A, f = spk.AssembleOperator_Laplace(M)
     if pc == "schur":
@@ -303,6 +304,8 @@ def test_every_iteration_form_against_the_oracle(spk, oracle, form, pc):
             c.set_block(spk.BLOCK_A10, B)
         c.pc_setup(spk.PC_SCHUR if B is not None else spk.PC_JACOBI, 3)
         x, info = c.fgmres(rhs, rtol=1e-9, iteration_form=form)
+        if form >= 5:
+            assert c.iteration_form()[0] == form    # (these two apply to this set-up: no silent fall-back)
         # -ksp_max_it ending the solve in the middle of a cycle (the host stops enqueuing there; the last Givens step
         # of the form -- a rider, the next head, the cycle end -- must still have run)
         _, tr = c.fgmres(rhs, rtol=1e-30, max_it=47, iteration_form=form)
