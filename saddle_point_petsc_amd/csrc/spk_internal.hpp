@@ -681,6 +681,7 @@ struct ResidentArgs {
 };
 bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t *done, hipStream_t s);   // false: shape does not fit
 int64_t resident_scratch_doubles(int num_cus, int mk);
+bool resident_fits(const DictDev &A, int num_cus, int mk, int planes);   // planes: dense planes of B D the iteration streams
 // block-column range of every tile of the blocked matrix (set-up of the BA kernel's neighbour lists)
 void tile_col_range(const int32_t *browptr, const int32_t *bcol, const int32_t *tile_brow, int ntiles, int32_t *out, hipStream_t s);
 int iter_maxpy_uhead(IterB b, hipStream_t s);   // returns the number of partial rows (GivensRider::fin_n)

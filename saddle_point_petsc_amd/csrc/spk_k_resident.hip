@@ -27,22 +27,25 @@ namespace spk {
 namespace k {
 
 constexpr int kResMaxV = 31;   // basis vectors a thread holds (restart <= 30)
-constexpr int kResLd = 64;     // doubles per workgroup and iteration in the all-to-all buffer; [63] = ||w'||^2 partial
+constexpr int kResLd = 64;     // values per iteration in the all-to-all buffer (<= kResMaxVals used)
+constexpr int kResG = 256;     // workgroups (one per CU); the buffer is [iteration][value][workgroup]: a reader's 8 partials are contiguous
 
 __device__ __forceinline__ bool res_timed_out(unsigned long long t0, uint32_t ticks) { return wall_clock64() - t0 > (unsigned long long)ticks; }
 
 // One Arnoldi step's scalar work on the workgroup's OWN copy of the Krylov scalars (every workgroup runs it on the same
-// inputs); the master also writes what krylov_cycle_end and the host read.  Semantics of givens_block_lds (spk_device.hpp).
-__device__ __forceinline__ void res_givens(KrylovState &L, const KrylovArrays &ka, int loc, const double *hcol, double nrm2,
-                                           double *cc, double *ss, double *rs, double *Hr, bool master)
+// inputs).  Semantics of givens_block_lds (spk_device.hpp).  Hr: the rotated column (loc + 2 entries), kept for the flush.
+__device__ __forceinline__ void res_givens(KrylovState &L, int loc, const double *__restrict__ hcol, double nrm2,
+                                           double *__restrict__ cc, double *__restrict__ ss, double *__restrict__ rs,
+                                           double *__restrict__ Hr)
 {
     const double rs_loc = rs[loc];
     const double tt = sqrt(nrm2);
+    L.hapend = 0;
     if (isnan(tt) || isinf(tt)) {
         L.rnorm = tt;
         L.reason = SPK_DIVERGED_NANORINF;
         L.done = L.skip_iter = 1;
-        if (master) *ka.st = L;
+        L.hapend = -1;   // (flush: nothing but the state)
         return;
     }
     double hapbnd = fabs(tt / rs_loc);
@@ -51,6 +54,7 @@ __device__ __forceinline__ void res_givens(KrylovState &L, const KrylovArrays &k
     L.tt = tt;
     L.inv_tt = hapend ? 1.0 : 1.0 / tt;
     double run = hcol[0];
+#pragma unroll 4
     for (int j = 1; j <= loc; ++j) {
         const double h1 = hcol[j], cj = cc[j - 1], sj = ss[j - 1];
         Hr[j - 1] = cj * run + sj * h1;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void res_givens(KrylovState &L, const KrylovArrays &k
         if (d == 0.0) {
             L.reason = SPK_DIVERGED_NULL;
             L.done = L.skip_iter = 1;
-            if (master) *ka.st = L;
+            L.hapend = -1;
             return;
         }
         const double c = h0 / d, sn = h1 / d;
@@ -85,71 +89,94 @@ __device__ __forceinline__ void res_givens(KrylovState &L, const KrylovArrays &k
     if (!reason && L.its >= L.max_it) reason = SPK_DIVERGED_ITS;
     L.reason = reason;
     if (reason) L.done = L.skip_iter = 1;
-    if (master) {
+}
+// what krylov_cycle_end and the host read of that step (master workgroup, off the critical path)
+__device__ __forceinline__ void res_givens_flush(const KrylovState &L, const KrylovArrays &ka, int loc, const double *Hr,
+                                                 const double *cc, const double *ss, const double *rs)
+{
+    if (L.hapend >= 0) {
         double *Hg = ka.H + (size_t)ka.ldh * loc;
         for (int j = 0; j <= loc + 1; ++j) Hg[j] = Hr[j];
-        if (!hapend) {
+        if (!L.hapend) {
             ka.cc[loc] = cc[loc];
             ka.ss[loc] = ss[loc];
             ka.rs[loc + 1] = rs[loc + 1];
             ka.rs[loc] = rs[loc];
         }
-        if (L.its < ka.hist_cap) ka.hist[L.its] = rnorm;
-        *ka.st = L;
+        if (L.its < ka.hist_cap) ka.hist[L.its] = L.rnorm;
     }
+    KrylovState o = L;
+    if (o.hapend < 0) o.hapend = 0;
+    *ka.st = o;
 }
 
 struct ResArgs {
     DictArgs d;
     int G, rpw;            // workgroups; block rows per workgroup (<= T)
     int mk, m, np, packed, fact, lam_in_dot;   // np: planes of B D actually present (<= NP of the instantiation)
+    int nwide;             // block positions with 32-bit codes
     int64_t nl, ld;
     const double *V0, *V1; // v_0 (normalised) and w~ = K z_0 (first product of the cycle, made by the launches before)
     double *Z;             // Z_j = Z + j ld: Z_1 .. written here (rows armed with the sentinel)
     const double *dinv, *bd;
     int64_t ldb;
     const double *shat, *gram;
-    double *P;             // all-to-all buffer, (mk + 1) x G x kResLd, armed
+    double *P;             // all-to-all buffer, (mk + 1) x kResLd x kResG, armed
     KrylovArrays ka;
     double *sc_out;        // scale factors of the un-normalised basis (krylov_cycle_end)
     int32_t *err;
     uint32_t ticks;
     int tab_bytes;         // LDS bytes of the matrix tables (16-byte multiple)
+#ifdef SPK_RES_STAMPS
+    unsigned long long *stamps;   // developer build: 100 MHz time stamps of the phases of iterations 10 and 25, per workgroup
+#endif
 };
+#ifdef SPK_RES_STAMPS
+#define RES_STAMP(k_) do { if (t == 0 && (loc == 10 || loc == 25)) a.stamps[((size_t)wg * 2 + (loc == 25)) * 8 + (k_)] = wall_clock64(); } while (0)
+#else
+#define RES_STAMP(k_) do { } while (0)
+#endif
+
+constexpr int kResPass = 20;      // inner products reduced per pass through the LDS staging
+constexpr int kResMaxVals = 40;   // nv + m + 1 <= 30 + 8 + 1
 
 // NP: planes of B D a thread holds (0: K = A; packed: m = 2 NP, dense: m = NP)
 template <int T, int NP>
 __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
 {
-    constexpr int W = T / kWave;
+    constexpr int LDP = T + 8;                                   // row stride of the product staging (bank shift per row)
+    constexpr int MAXIT = (kResMaxVals * 32 + T - 1) / T;        // all-to-all items (value, chunk of 8 workgroups) per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // ---- LDS: matrix tables, then the scalar work space (all doubles)
-    double *ws = reinterpret_cast<double *>(smem + a.tab_bytes);
-    double *red = ws;                       // W x 64
-    double *dots = red + W * kResLd;        // 64
+    // ---- LDS: matrix tables | code planes of this workgroup's rows | product staging | scalar work space
+    int2v *clo = reinterpret_cast<int2v *>(smem + a.tab_bytes);  // kmax x T low halves, then nwide x T high halves
+    int2v *chi = clo + (size_t)a.d.kmax * T;
+    double *prod = reinterpret_cast<double *>(chi + (size_t)a.nwide * T);   // kResPass x LDP; also the all-to-all partials
+    double *ws = prod + kResPass * LDP;
+    double *dots = ws;                      // 64
     double *hs = dots + 64;                 // 32: MAXPY coefficients h_i sc_i
-    double *hcol = hs + 32;                 // 34: Hessenberg column of the iteration (scaled)
-    double *scl = hcol + 34;                // 34: scale factors
-    double *gcc = scl + 34, *gss = gcc + 34, *grs = gss + 34, *gHr = grs + 34;   // rotations, rhs, column scratch
+    double *hcolb = hs + 32;                // 2 x 34: Hessenberg column (scaled), by iteration parity
+    double *scl = hcolb + 68;               // 34: scale factors
+    double *gcc = scl + 34, *gss = gcc + 34, *grs = gss + 34, *gHr = grs + 34;   // rotations, rhs, rotated column
     double *lamV = gHr + 34;                // 32 x 8: multiplier entries of the basis vectors
     double *tbl = lamV + 32 * 8;            // 32 x 8: B D V~_i
     double *ys = tbl + 32 * 8, *wraws = ys + 8, *tus = wraws + 8, *w1s = tus + 8, *wl = w1s + 8, *shs = wl + 8;   // 8 each
     double *grm = shs + 8;                  // 64
     KrylovState *L = reinterpret_cast<KrylovState *>(grm + 64);
-    int *flag = reinterpret_cast<int *>(L + 1);   // [0] stop (done / timed out)
+    int *flag = reinterpret_cast<int *>(L + 1);   // [0] stop (done / timed out), [1] Givens step waiting for its flush
 
-    const int wg = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wg = blockIdx.x, t = threadIdx.x;
     const int m = a.m, mk = a.mk;
     const bool master = wg == 0;
     const int64_t br = (int64_t)wg * a.rpw + t;
     const bool active = t < a.rpw && br < a.d.nbrows;
-    const double armed = __longlong_as_double((long long)kSentinelBits);
+    constexpr int TG = T - kWave;   // the thread that runs the Givens steps (lane 0 of the last wave: beside wave 0's scalar work)
 
-    // ---- prologue: state, tables, this thread's entries
+    // ---- prologue: state, tables, this thread's entries, this workgroup's matrix codes
     for (int i = t; i < (int)(reinterpret_cast<double *>(L) - ws); i += T) ws[i] = 0.0;
     if (t == 0) {
         *L = *a.ka.st;
         flag[0] = 0;
+        flag[1] = -1;
     }
     double2 V[kResMaxV];
 #pragma unroll
@@ -169,6 +196,17 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
         pe[q].x = pe[q].y = 0.0;
         if (active && q < a.np) pe[q] = ld2(a.bd + (size_t)q * a.ldb, br);
     }
+    {   // the codes of this thread's block row: read once per cycle, decoded out of LDS in every product
+        int wi = 0;
+        for (int k = 0; k < a.d.kmax; ++k) {
+            const int2v *p = reinterpret_cast<const int2v *>(a.d.codes + a.d.plane_off[k]);
+            clo[k * T + t] = active ? p[br] : int2v{0, 0};
+            if ((a.d.wide_mask >> k) & 1u) {
+                chi[wi * T + t] = active ? p[a.d.nbrows_pad + br] : int2v{0, 0};
+                ++wi;
+            }
+        }
+    }
     dict_load_lds(a.d, a.d.nclass * 4, smem);   // (ends with a barrier)
     if (L->done || L->skip_iter) return;         // uniform: set by krylov_cycle_begin before this launch
     if (t < m) {
@@ -187,143 +225,185 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
     const double2 *cv = reinterpret_cast<const double2 *>(smem + a.d.cls_off);
     const int len = active ? tlen[tid] : 0;
     const int2 *te = tent + (size_t)tid * a.d.kmax;
+    const int nch = (a.G + 7) / 8;
     __syncthreads();
 
     double nrmp = 0.0;   // this thread's share of ||w'||^2 of the previous iteration
     for (int loc = 0;; ++loc) {
         const int nv = loc + 1;
-        const int nvals = loc < mk ? nv + m : 0;
-        // ---- (a) partial inner products V~_i . w~ (raw: scaled where consumed), B D w~, and the pending norm
-        double *Pl = a.P + ((size_t)loc * a.G + wg) * kResLd;
-        if (loc < mk) {
+        const int nvt = (loc < mk ? nv + m : 0) + 1;   // values of this exchange: V~_i . w~ (raw), B D w~, and LAST the pending norm
+        RES_STAMP(0);
+        // ---- (a) this workgroup's partial sums: every thread stages its products in LDS, a few threads per value add
+        // them in a fixed order (no 64-lane shuffle chains: 36 values x 6 steps cost 5-9 us here)
+        double *Pl = a.P + (size_t)loc * kResLd * kResG + wg;   // value sl of this workgroup: Pl[sl * kResG]
+        for (int s0 = 0; s0 < nvt; s0 += kResPass) {
+            if (loc < mk) {
 #pragma unroll
-            for (int i = 0; i < kResMaxV - 1; ++i) {
-                if (i < nv) {   // uniform
-                    const double s = wave_sum(V[i].x * w.x + V[i].y * w.y);
-                    if (lane == 0) red[wave * kResLd + i] = s;
+                for (int i = 0; i < kResMaxV - 1; ++i)
+                    if (i < nv && i >= s0 && i < s0 + kResPass) prod[(i - s0) * LDP + t] = V[i].x * w.x + V[i].y * w.y;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (a.packed) {
+                        const int sl = nv + 2 * q;
+                        if (2 * q < m && sl >= s0 && sl < s0 + kResPass) prod[(sl - s0) * LDP + t] = pe[q].x * w.x;
+                        if (2 * q + 1 < m && sl + 1 >= s0 && sl + 1 < s0 + kResPass) prod[(sl + 1 - s0) * LDP + t] = pe[q].y * w.y;
+                    } else {
+                        const int sl = nv + q;
+                        if (q < m && sl >= s0 && sl < s0 + kResPass) prod[(sl - s0) * LDP + t] = pe[q].x * w.x + pe[q].y * w.y;
+                    }
                 }
             }
+            if (nvt - 1 >= s0 && nvt - 1 < s0 + kResPass) prod[(nvt - 1 - s0) * LDP + t] = nrmp;
+            __syncthreads();
+            const int nvp = min(kResPass, nvt - s0);
+            constexpr int TPV = T / 32;   // threads per value (16 | 8), 32 staged products each
+            if (t < TPV * nvp) {
+                const int sv = t / TPV, j = t % TPV;
+                const double *pr = prod + sv * LDP + j;
+                double a4[4] = {0.0, 0.0, 0.0, 0.0};   // four chains (a fixed order all the same): 8 dependent additions, not 32
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                if (a.packed) {
-                    const double s0 = wave_sum(pe[q].x * w.x), s1 = wave_sum(pe[q].y * w.y);
-                    if (lane == 0) {
-                        red[wave * kResLd + nv + 2 * q] = s0;
-                        red[wave * kResLd + nv + 2 * q + 1] = s1;
+                for (int k = 0; k < 32; ++k) a4[k & 3] += pr[TPV * k];
+                double acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+                if (TPV == 16) acc += __shfl_xor(acc, 8, kWave);
+                acc += __shfl_xor(acc, 4, kWave);
+                acc += __shfl_xor(acc, 2, kWave);
+                acc += __shfl_xor(acc, 1, kWave);
+                if (j == 0) {
+                    const int sl = s0 + sv;
+                    if (master && a.lam_in_dot) {   // the multiplier entries live in workgroup 0 (rank 0 counts them)
+                        if (sl < nvt - 1 && sl < nv)
+                            for (int r = 0; r < m; ++r) acc += lamV[sl * 8 + r] * wl[r];
+                        else if (sl == nvt - 1 && loc > 0)
+                            for (int r = 0; r < m; ++r) acc += wraws[r] * wraws[r];
                     }
-                } else {
-                    const double s0 = wave_sum(pe[q].x * w.x + pe[q].y * w.y);
-                    if (lane == 0) red[wave * kResLd + nv + q] = s0;
+                    publish(Pl + (size_t)sl * kResG, acc);
+                }
+            }
+            __syncthreads();
+        }
+        RES_STAMP(1);
+        // ---- (b) every workgroup reads ALL partials and adds them in ONE order: the same bits everywhere.  Work item =
+        // (value, chunk of 8 workgroups); all loads of a thread in flight together, asked again while a slot is still armed
+        {
+            const int nitems = nvt * nch;
+            double v[MAXIT][8];
+            const double *Pb = a.P + (size_t)loc * kResLd * kResG;
+            const unsigned long long t0 = wall_clock64();
+            bool miss;
+            do {
+                miss = false;
+#pragma unroll
+                for (int q = 0; q < MAXIT; ++q) {
+                    const int it = t + q * T;
+                    const int i = it / nch, c = it - i * nch;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int g = 8 * c + u;
+                        v[q][u] = (it < nitems && g < a.G) ? peek(Pb + (size_t)i * kResG + g) : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < MAXIT; ++q)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) miss = miss || is_sentinel(v[q][u]);
+                if (miss) {
+                    if (res_timed_out(t0, a.ticks) || flag[0]) {
+                        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } while (miss);
+#pragma unroll
+            for (int q = 0; q < MAXIT; ++q) {
+                const int it = t + q * T;
+                if (it < nitems) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += v[q][u];
+                    prod[it] = acc;   // [value][chunk]
                 }
             }
         }
-        {
-            const double s = wave_sum(nrmp);
-            if (lane == 0) red[wave * kResLd + 63] = s;
-        }
         __syncthreads();
-        if (t < nvals || t == 63) {
+        if (t < nvt) {
             double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < W; ++j) s += red[j * kResLd + t];
-            if (master && a.lam_in_dot) {   // the multiplier entries live in workgroup 0 (rank 0 counts them)
-                if (t < nv)
-                    for (int r = 0; r < m; ++r) s += lamV[t * 8 + r] * wl[r];
-                else if (t == 63 && loc > 0)
-                    for (int r = 0; r < m; ++r) s += wraws[r] * wraws[r];
-            }
-            publish(Pl + t, s);
-        }
-        __syncthreads();
-        // ---- every workgroup reads ALL partials and adds them in workgroup order: the same bits everywhere
-        {
-            const int i = lane;
-            const bool live = i < nvals || i == 63;
-            double acc = 0.0;
-            const double *Pi = a.P + (size_t)loc * a.G * kResLd + i;
-            constexpr int B = 8;
-            for (int g0 = wave; g0 < a.G; g0 += W * B) {
-                double v[B];
-                const unsigned long long t0 = wall_clock64();
-                bool miss;
-                do {
-                    miss = false;
-#pragma unroll
-                    for (int u = 0; u < B; ++u) {
-                        const int g = g0 + u * W;
-                        v[u] = (live && g < a.G) ? peek(Pi + (size_t)g * kResLd) : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < B; ++u) miss = miss || is_sentinel(v[u]);
-                    if (miss) {
-                        if (res_timed_out(t0, a.ticks) || flag[0]) {
-                            __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            flag[0] = 1;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                } while (miss);
-#pragma unroll
-                for (int u = 0; u < B; ++u) acc += v[u];
-            }
-            red[wave * kResLd + i] = acc;
-        }
-        __syncthreads();
-        if (t < 64) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < W; ++j) s += red[j * kResLd + t];
+            for (int c = 0; c < nch; ++c) s += prod[t * nch + c];
             dots[t] = s;
         }
         __syncthreads();
-        // ---- scalar work, every workgroup for itself: first what was pending of iteration loc - 1
-        if (t == 0 && !flag[0] && loc > 0) {
-            const double nrm2 = dots[63];
-            scl[loc] = inv_norm(nrm2);
-            res_givens(*L, a.ka, loc - 1, hcol, nrm2, gcc, gss, grs, gHr, master);
+        RES_STAMP(2);
+        // ---- (c) scalar work, every workgroup for itself.  Pending of iteration loc - 1: its norm has just arrived, so
+        // its Givens step runs now -- in the LAST wave, beside wave 0's work for this iteration
+        const double nrm2 = dots[nvt - 1];
+        if (t == TG && !flag[0] && loc > 0) {
+            res_givens(*L, loc - 1, hcolb + 34 * ((loc - 1) & 1), nrm2, gcc, gss, grs, gHr);
+            flag[1] = loc - 1;
             if (L->done || L->skip_iter) flag[0] = 1;
+        }
+        const double s_w = loc > 0 ? inv_norm(nrm2) : 1.0;   // scale factor of V~_loc (v_0 is normalised)
+        if (t < kWave && loc < mk) {   // lane i owns basis vector i; the m-vectors are finished inside this wave
+            const int i = t;
+            double *hcol = hcolb + 34 * (loc & 1);
+            const double sci = i < nv ? (i == loc ? s_w : scl[i]) : 0.0;
+            const double hi = i < nv ? sci * s_w * dots[i] : 0.0;
+            const double ci = hi * sci;
+            if (i == 0) scl[loc] = s_w;
+            if (i < nv) {
+                hs[i] = ci;
+                hcol[i] = hi;
+            }
+            double tu = 0.0, wraw = 0.0;   // lane r < m: B D w' and the multiplier entry of w'
+            constexpr int MM = 2 * NP;     // rows this instantiation may carry (m <= MM)
+            if (MM > 0) {
+                double tsv[MM > 0 ? MM : 1], lsv[MM > 0 ? MM : 1];
+#pragma unroll
+                for (int r = 0; r < MM; ++r) {
+                    tsv[r] = (i < nv && r < m) ? hi * (tbl[i * 8 + r] * sci) : 0.0;   // sum h_i (B D v_i)
+                    lsv[r] = (i < nv && r < m) ? ci * lamV[i * 8 + r] : 0.0;           // the MAXPY of the multiplier entries
+                }
+                // the 2 m wave sums side by side (one after the other they were 2 us of dependent shuffles)
+#pragma unroll
+                for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+                    for (int r = 0; r < MM; ++r) {
+                        tsv[r] += __shfl_down(tsv[r], off, kWave);
+                        lsv[r] += __shfl_down(lsv[r], off, kWave);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < MM; ++r) {
+                    const double tsum0 = __shfl(tsv[r], 0, kWave), lsum0 = __shfl(lsv[r], 0, kWave);
+                    if (i == r && r < m) {
+                        tu = dots[nv + r] * s_w - tsum0;   // B D w' = B D w - sum h_i (B D v_i)
+                        wraw = s_w * wl[r] - lsum0;
+                    }
+                }
+            }
+            const double y = i < m ? -(wraw - tu) / shs[i] : 0.0;
+            double w1 = tu;
+            if (a.fact == SPK_SCHUR_FULL) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < m) {   // uniform
+                        const double yq = __shfl(y, q, kWave);
+                        if (i < m) w1 -= grm[i * m + q] * yq;
+                    }
+            }
+            if (i < m) {
+                ys[i] = y;
+                wraws[i] = wraw;
+                w1s[i] = w1;
+                lamV[nv * 8 + i] = wraw;
+                tbl[nv * 8 + i] = tu;
+                if (master && loc + 1 < mk) a.Z[(size_t)(loc + 1) * a.ld + a.nl + i] = y;
+            }
         }
         __syncthreads();
         if (flag[0] || loc >= mk) break;
-        const double s_w = scl[loc];
-        if (t < kWave) {   // lane i owns basis vector i
-            const int i = t;
-            const double sci = i < nv ? scl[i] : 0.0;
-            const double hi = i < nv ? sci * s_w * dots[i] : 0.0;
-            if (i < nv) {
-                hs[i] = hi * sci;
-                hcol[i] = hi;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (r < m) {   // uniform
-                    const double tsum = wave_sum(hi * (i < nv ? tbl[i * 8 + r] * sci : 0.0));
-                    if (i == 0) tus[r] = dots[nv + r] * s_w - tsum;   // B D w' = B D w - sum h_i (B D v_i)
-                }
-            }
-        }
-        __syncthreads();
-        if (t < m) {
-            const int r = t;
-            double wraw = s_w * wl[r];
-            for (int i = 0; i < nv; ++i) wraw += -hs[i] * lamV[i * 8 + r];   // the MAXPY of the multiplier entries
-            const double y = -(wraw - tus[r]) / shs[r];
-            wraws[r] = wraw;
-            ys[r] = y;
-        }
-        __syncthreads();
-        if (t < m) {
-            const int r = t;
-            double w1 = tus[r];
-            if (a.fact == SPK_SCHUR_FULL)
-                for (int q = 0; q < m; ++q) w1 -= grm[r * m + q] * ys[q];
-            w1s[r] = w1;
-            lamV[nv * 8 + r] = wraws[r];
-            tbl[nv * 8 + r] = tus[r];
-            if (master && loc + 1 < mk) a.Z[(size_t)(loc + 1) * a.ld + a.nl + r] = ys[r];
-        }
-        // ---- VecMAXPY in registers, the norm's share, the next PCApply (+ B^T part of the next product)
+        RES_STAMP(3);
+        // ---- (d) VecMAXPY in registers, the norm's share, the next PCApply (+ B^T part of the next product)
         w.x *= s_w;
         w.y *= s_w;
 #pragma unroll
@@ -345,6 +425,10 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
         if (loc + 1 >= mk) {   // last iteration of the cycle: only its norm is still wanted
             __syncthreads();
             if (t < m) wl[t] = w1s[t];
+            if (master && t == TG && flag[1] >= 0) {
+                res_givens_flush(*L, a.ka, flag[1], gHr, gcc, gss, grs);
+                flag[1] = -1;
+            }
             continue;
         }
         double2 sv, zz, cc;
@@ -377,14 +461,14 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
         }
         __syncthreads();   // (ys, w1s read above by everybody; the multiplier entries of the next w~)
         if (t < m) wl[t] = w1s[t];
-        // ---- MatMult: w~ = A z~ (+ c~), rows of z~ gathered as their owners publish them
+        RES_STAMP(4);
+        // ---- (e) MatMult: w~ = A z~ (+ c~), rows of z~ gathered as their owners publish them
         if (active) {
 #pragma clang fp contract(off)   // every product rounded on its own, added in CSR order (spk_k_dict.hip)
             double s0 = 0.0, s1 = 0.0;
             constexpr int G9 = 9;
             for (int k0 = 0; k0 < len; k0 += G9) {
                 int2 e[G9];
-                DictRaw<2> raw[G9];
                 double xv[G9][2];
 #pragma unroll
                 for (int g = 0; g < G9; ++g) {
@@ -392,7 +476,6 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                     e[g] = in ? te[k0 + g] : make_int2(0, 0);
                     xv[g][0] = xv[g][1] = 0.0;
                     if (in) {
-                        dict_issue<2>(a.d, k0 + g, br, raw[g]);
                         const int64_t c = br + e[g].x;
                         xv[g][0] = ld_agent(Zn + 2 * c);
                         xv[g][1] = ld_agent(Zn + 2 * c + 1);
@@ -420,9 +503,14 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
 #pragma unroll
                 for (int g = 0; g < G9; ++g) {
                     if (k0 + g < len) {
+                        const int k = k0 + g;
                         const double2 *cb = cv + (size_t)e[g].y * 4;
+                        DictRaw<2> raw;
+                        raw.lo[0] = clo[k * T + t];
+                        raw.hi[0] = int2v{0, 0};
+                        if ((a.d.wide_mask >> k) & 1u) raw.hi[0] = chi[__builtin_popcount(a.d.wide_mask & ((1u << k) - 1u)) * T + t];
                         int code[4];
-                        dict_unpack<2>(raw[g], code);
+                        dict_unpack<2>(raw, code);
                         s0 += dict_decode(code[0], cb[0]) * xv[g][0];
                         s0 += dict_decode(code[1], cb[1]) * xv[g][1];
                         s1 += dict_decode(code[2], cb[2]) * xv[g][0];
@@ -437,11 +525,20 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             w.x = s0;
             w.y = s1;
         }
+        // (what krylov_cycle_end and the host read of the Givens step taken above: written here, off the critical path)
+        if (master && t == TG && flag[1] >= 0) {
+            res_givens_flush(*L, a.ka, flag[1], gHr, gcc, gss, grs);
+            flag[1] = -1;
+        }
+        RES_STAMP(5);
         __syncthreads();
+        RES_STAMP(6);
+    }
+    if (master && t == TG) {
+        if (flag[1] >= 0) res_givens_flush(*L, a.ka, flag[1], gHr, gcc, gss, grs);
     }
     // the scale factors for krylov_cycle_end (x += sum y_i sc_i Z~_i)
     if (master && t <= mk) a.sc_out[t] = t <= L->loc_done ? scl[t] : 1.0;
-    (void)armed;
 }
 
 // sentinel into the all-to-all buffer and into rows [0, nl) of Z_1 .. Z_{nvec}
@@ -456,57 +553,106 @@ __global__ __launch_bounds__(kThreads) void res_arm_kernel(double *P, int64_t nP
     for (int64_t i = i0; i < nz; i += stride) Z[(i / nl + 1) * ld + i % nl] = armed;
 }
 
+static int res_threads(int rpw) { return rpw <= 256 ? 256 : 512; }
 size_t resident_lds_bytes(const DictDev &A, int T)
 {
     const size_t tab = ((size_t)A.lds_bytes + 15) & ~(size_t)15;
-    const size_t dbl = (size_t)(T / kWave) * kResLd + 64 + 32 + 34 * 6 + 32 * 8 * 2 + 8 * 6 + 64;
-    return tab + dbl * sizeof(double) + sizeof(KrylovState) + 64;
+    const size_t codes = (size_t)(A.kmax + __builtin_popcount(A.wide_mask)) * T * 8;
+    const size_t dbl = (size_t)kResPass * (T + 8) + 64 + 32 + 68 + 34 * 5 + 32 * 8 * 2 + 8 * 6 + 64;
+    return tab + codes + dbl * sizeof(double) + sizeof(KrylovState) + 64;
+}
+// does the resident cycle kernel take this system?  (np: planes of B D)
+bool resident_fits(const DictDev &A, int num_cus, int mk, int np)
+{
+    if (!A.ok || A.bs != 2 || num_cus < 1 || A.nbrows < 1) return false;
+    const int G = (int)std::min<int64_t>(std::min(num_cus, 256), ((int64_t)A.nbrows + 63) / 64);
+    const int rpw = (A.nbrows + G - 1) / G;
+    if (rpw > 512 || mk > kResMaxV - 1 || mk < 2 || np > 4) return false;
+    return resident_lds_bytes(A, res_threads(rpw)) <= 160 * 1024;
 }
 
-// host side: arguments checked by the caller (spk_solver.cpp); returns false when the launch shape does not fit
+// host side: arguments checked by the caller (spk_solver.cpp: resident_fits)
 bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t *done, hipStream_t s)
 {
-    if (A.bs != 2 || !A.ok) return false;
-    const int G = std::min<int64_t>(num_cus, ((int64_t)A.nbrows + 63) / 64);
-    const int rpw = (A.nbrows + G - 1) / G;
-    if (rpw > 512 || r.mk > kResMaxV - 1) return false;
-    const int T = rpw <= 256 ? 256 : 512;
     const int np = r.m == 0 ? 0 : (r.packed ? r.m / 2 : r.m);
-    if (np > 4) return false;
+    if (!resident_fits(A, num_cus, r.mk, np)) return false;
+    const int G = (int)std::min<int64_t>(std::min(num_cus, 256), ((int64_t)A.nbrows + 63) / 64);
+    const int rpw = (A.nbrows + G - 1) / G;
+    const int T = res_threads(rpw);
     int dummy = 0;
     ResArgs a{};
     a.d = dict_args(A, &dummy);
     a.G = G;
     a.rpw = rpw;
     a.mk = r.mk; a.m = r.m; a.np = np; a.packed = r.packed; a.fact = r.fact; a.lam_in_dot = r.lam_in_dot;
+    a.nwide = __builtin_popcount(A.wide_mask);
     a.nl = r.nl; a.ld = r.ld;
     a.V0 = r.V0; a.V1 = r.V1; a.Z = r.Z; a.dinv = r.dinv; a.bd = r.bd; a.ldb = r.ldb; a.shat = r.shat; a.gram = r.gram;
     a.P = r.P; a.ka = r.ka; a.sc_out = r.sc_out; a.err = r.err; a.ticks = r.ticks;
     a.tab_bytes = (int)(((size_t)A.lds_bytes + 15) & ~(size_t)15);
+#ifdef SPK_RES_STAMPS
+    static unsigned long long *stamp_buf = nullptr;
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, 8 * 16 * 1024);
+    a.stamps = stamp_buf;
+#endif
     const size_t lds = resident_lds_bytes(A, T);
     // arm: the all-to-all buffer of this cycle and the rows of Z the product gathers
     {
-        const int64_t nP = (int64_t)(r.mk + 1) * G * kResLd;
+        const int64_t nP = (int64_t)(r.mk + 1) * kResG * kResLd;
         const int64_t tot = std::max<int64_t>(nP, r.nl * (int64_t)(r.mk - 1));
         const int grid = (int)std::min<int64_t>((tot + kThreads - 1) / kThreads, 4096);
         hipLaunchKernelGGL(res_arm_kernel, dim3(std::max(grid, 1)), dim3(kThreads), 0, s, r.P, nP, r.Z, r.ld, r.nl, r.mk - 1, done);
     }
-#define SPK_RES(TT, NPP) hipLaunchKernelGGL((cycle_resident_kernel<TT, NPP>), dim3(G), dim3(TT), lds, s, a)
+    static bool attr_set[6] = {false, false, false, false, false, false};
+#define SPK_RES(TT, NPP, IDX)                                                                                                       \
+    do {                                                                                                                            \
+        if (!attr_set[IDX]) {   /* more than 64 KB of dynamic LDS has to be asked for */                                            \
+            SPK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cycle_resident_kernel<TT, NPP>),                            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                   \
+            attr_set[IDX] = true;                                                                                                   \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((cycle_resident_kernel<TT, NPP>), dim3(G), dim3(TT), lds, s, a);                                         \
+    } while (0)
     const int npt = np == 0 ? 0 : (np <= 2 ? 2 : 4);
     if (T == 256) {
-        if (npt == 0) SPK_RES(256, 0);
-        else if (npt == 2) SPK_RES(256, 2);
-        else SPK_RES(256, 4);
+        if (npt == 0) SPK_RES(256, 0, 0);
+        else if (npt == 2) SPK_RES(256, 2, 1);
+        else SPK_RES(256, 4, 2);
     } else {
-        if (npt == 0) SPK_RES(512, 0);
-        else if (npt == 2) SPK_RES(512, 2);
-        else SPK_RES(512, 4);
+        if (npt == 0) SPK_RES(512, 0, 3);
+        else if (npt == 2) SPK_RES(512, 2, 4);
+        else SPK_RES(512, 4, 5);
     }
 #undef SPK_RES
+#ifdef SPK_RES_STAMPS
+    {
+        static int shown = 0;
+        if (shown++ == 3) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)G * 16);
+            (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+            const char *nm[6] = {"dots+publish", "all-to-all", "scalars", "maxpy+z", "spmv(own)", "barrier"};
+            for (int which = 0; which < 2; ++which) {
+                fprintf(stderr, "[resident stamps, loc %d, G %d, T %d] us:", which ? 25 : 10, G, T);
+                for (int ph = 0; ph < 6; ++ph) {
+                    double sum = 0, mx = 0;
+                    for (int g = 0; g < G; ++g) {
+                        const double dt = (double)(h[((size_t)g * 2 + which) * 8 + ph + 1] - h[((size_t)g * 2 + which) * 8 + ph]) / 100.0;
+                        sum += dt; mx = dt > mx ? dt : mx;
+                    }
+                    fprintf(stderr, "  %s %.2f (max %.2f)", nm[ph], sum / G, mx);
+                }
+                unsigned long long lo = ~0ull, hi = 0;
+                for (int g = 0; g < G; ++g) { lo = std::min(lo, h[((size_t)g * 2 + which) * 8]); hi = std::max(hi, h[((size_t)g * 2 + which) * 8]); }
+                fprintf(stderr, "  | entry skew %.2f\n", (double)(hi - lo) / 100.0);
+            }
+        }
+    }
+#endif
     return true;
 }
 
-int64_t resident_scratch_doubles(int num_cus, int mk) { return (int64_t)(mk + 1) * num_cus * kResLd; }
+int64_t resident_scratch_doubles(int num_cus, int mk) { (void)num_cus; return (int64_t)(mk + 1) * kResG * kResLd; }
 
 }  // namespace k
 }  // namespace spk

@@ -1246,8 +1246,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const int res_planes = !fused ? 0 : (bpk ? m / 2 : m);
     const bool resident = un3 && (form == SPK_ITER_RESIDENT || (form == SPK_ITER_AUTO && !res_env_off)) && c->comm->size() == 1 &&
                           c->peers.empty() && c->n_ghost == 0 && c->spmv_format == 1 && c->Adict.ok && c->Adict.bs == 2 &&
-                          nl % 2 == 0 && mk <= 30 && mk >= 2 && res_planes <= 4 && c->num_cus > 0 &&
-                          (int64_t)c->Adict.nbrows <= (int64_t)c->num_cus * 512;
+                          nl % 2 == 0 && k::resident_fits(c->Adict, c->num_cus, mk, res_planes);
     if (resident) {
         const size_t need = (size_t)k::resident_scratch_doubles(c->num_cus, mk);
         if (c->res_P.n < need) c->res_P.alloc(need);
