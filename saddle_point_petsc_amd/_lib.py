@@ -70,12 +70,52 @@ class MatCSR(C.Structure):
     ]
 
 
+def hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (two = two HIP runtimes: the second finds no device)."""
+    try:
+        with open("/proc/self/maps") as fh:
+            return sorted({ln.split()[-1] for ln in fh if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
+def _preload_hip_runtime():
+    """ONE HIP runtime per process whatever the import order.  The torch wheel carries a private libamdhip64.so (SONAME
+    libamdhip64.so.7, the name libspk.so needs).  Loaded first, it satisfies libspk's dependency by soname; loaded SECOND --
+    `import saddle_point_petsc_amd` before `import torch` -- the process used to map two runtimes, and the second one found
+    no device ("no ROCm-capable device").  So where torch is installed its copy is mapped here, before libspk.so, without
+    importing torch; a later `import torch` finds it already loaded.  SPK_HIP_RUNTIME=system keeps /opt/rocm's."""
+    if os.environ.get("SPK_HIP_RUNTIME") == "system":
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
             "(hipcc, gfx950).  saddle_point_petsc_amd has no CPU fallback.")
+    global _hip_preloaded
+    _hip_preloaded = _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
+    rts = hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise ImportError("two HIP runtimes are mapped into this process (" + ", ".join(rts) + "): libspk.so would not find the "
+                          "GPU.  Import saddle_point_petsc_amd before anything else that loads a HIP runtime of its own, or set "
+                          "LD_LIBRARY_PATH so that both resolve libamdhip64.so.7 to the same file.")
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.spk_version.restype = C.c_int
     L.spk_last_error.restype = C.c_char_p
@@ -164,4 +204,5 @@ def _load():
     return L
 
 
+_hip_preloaded = None
 lib = _load()

@@ -30,6 +30,12 @@ constexpr int kResMaxV = 31;   // basis vectors a thread holds (restart <= 30)
 constexpr int kResLd = 64;     // values per iteration in the all-to-all buffer (<= kResMaxVals used)
 constexpr int kResG = 256;     // workgroups (one per CU); the buffer is [iteration][value][workgroup]: a reader's 8 partials are contiguous
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a release fence first: it also waits for every
+// outstanding GLOBAL access of the wave (vmcnt(0)) -- here the write-through stores of partial sums and of z~, a trip to
+// memory each (measured: ~1.5 us per barrier behind such a store).  What other workgroups read is handed over by polling,
+// so inside the iteration loop only the LDS counter has to drain.
+__device__ __forceinline__ void bar_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ bool res_timed_out(unsigned long long t0, uint32_t ticks) { return wall_clock64() - t0 > (unsigned long long)ticks; }
 
 // One Arnoldi step's scalar work on the workgroup's OWN copy of the Krylov scalars (every workgroup runs it on the same
@@ -132,7 +138,7 @@ struct ResArgs {
 #endif
 };
 #ifdef SPK_RES_STAMPS
-#define RES_STAMP(k_) do { if (t == 0 && (loc == 10 || loc == 25)) a.stamps[((size_t)wg * 2 + (loc == 25)) * 8 + (k_)] = wall_clock64(); } while (0)
+#define RES_STAMP(k_) do { if (t == 0 && (loc == 10 || loc == 25)) a.stamps[((size_t)wg * 2 + (loc == 25)) * 16 + (k_)] = wall_clock64(); } while (0)
 #else
 #define RES_STAMP(k_) do { } while (0)
 #endif
@@ -238,9 +244,15 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
         double *Pl = a.P + (size_t)loc * kResLd * kResG + wg;   // value sl of this workgroup: Pl[sl * kResG]
         for (int s0 = 0; s0 < nvt; s0 += kResPass) {
             if (loc < mk) {
+                // (no test per vector: the entries of V~_i beyond the current basis are zero, their slots are either not
+                // read or overwritten just below -- thirty tests and branches cost more than the products)
+                if (s0 == 0) {
 #pragma unroll
-                for (int i = 0; i < kResMaxV - 1; ++i)
-                    if (i < nv && i >= s0 && i < s0 + kResPass) prod[(i - s0) * LDP + t] = V[i].x * w.x + V[i].y * w.y;
+                    for (int i = 0; i < kResPass; ++i) prod[i * LDP + t] = V[i].x * w.x + V[i].y * w.y;
+                } else {
+#pragma unroll
+                    for (int i = kResPass; i < kResMaxV - 1; ++i) prod[(i - kResPass) * LDP + t] = V[i].x * w.x + V[i].y * w.y;
+                }
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     if (a.packed) {
@@ -254,7 +266,9 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                 }
             }
             if (nvt - 1 >= s0 && nvt - 1 < s0 + kResPass) prod[(nvt - 1 - s0) * LDP + t] = nrmp;
-            __syncthreads();
+            if (s0 == 0) RES_STAMP(8);
+            bar_lds();
+            if (s0 == 0) RES_STAMP(9);
             const int nvp = min(kResPass, nvt - s0);
             constexpr int TPV = T / 32;   // threads per value (16 | 8), 32 staged products each
             if (t < TPV * nvp) {
@@ -279,7 +293,9 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                     publish(Pl + (size_t)sl * kResG, acc);
                 }
             }
-            __syncthreads();
+            if (s0 == 0) RES_STAMP(10);
+            bar_lds();
+            if (s0 == 0) RES_STAMP(11);
         }
         RES_STAMP(1);
         // ---- (b) every workgroup reads ALL partials and adds them in ONE order: the same bits everywhere.  Work item =
@@ -326,13 +342,13 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                 }
             }
         }
-        __syncthreads();
+        bar_lds();
         if (t < nvt) {
             double s = 0.0;
             for (int c = 0; c < nch; ++c) s += prod[t * nch + c];
             dots[t] = s;
         }
-        __syncthreads();
+        bar_lds();
         RES_STAMP(2);
         // ---- (c) scalar work, every workgroup for itself.  Pending of iteration loc - 1: its norm has just arrived, so
         // its Givens step runs now -- in the LAST wave, beside wave 0's work for this iteration
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                 if (master && loc + 1 < mk) a.Z[(size_t)(loc + 1) * a.ld + a.nl + i] = y;
             }
         }
-        __syncthreads();
+        bar_lds();
         if (flag[0] || loc >= mk) break;
         RES_STAMP(3);
         // ---- (d) VecMAXPY in registers, the norm's share, the next PCApply (+ B^T part of the next product)
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             nrmp += w.y * w.y;
         }
         if (loc + 1 >= mk) {   // last iteration of the cycle: only its norm is still wanted
-            __syncthreads();
+            bar_lds();
             if (t < m) wl[t] = w1s[t];
             if (master && t == TG && flag[1] >= 0) {
                 res_givens_flush(*L, a.ka, flag[1], gHr, gcc, gss, grs);
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             st_agent(Zn + 2 * br, zz.x);
             st_agent(Zn + 2 * br + 1, zz.y);
         }
-        __syncthreads();   // (ys, w1s read above by everybody; the multiplier entries of the next w~)
+        bar_lds();   // (ys, w1s read above by everybody; the multiplier entries of the next w~)
         if (t < m) wl[t] = w1s[t];
         RES_STAMP(4);
         // ---- (e) MatMult: w~ = A z~ (+ c~), rows of z~ gathered as their owners publish them
@@ -531,7 +547,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             flag[1] = -1;
         }
         RES_STAMP(5);
-        __syncthreads();
+        bar_lds();
         RES_STAMP(6);
     }
     if (master && t == TG) {
@@ -592,7 +608,7 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
     a.tab_bytes = (int)(((size_t)A.lds_bytes + 15) & ~(size_t)15);
 #ifdef SPK_RES_STAMPS
     static unsigned long long *stamp_buf = nullptr;
-    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, 8 * 16 * 1024);
+    if (!stamp_buf) (void)hipMalloc((void **)&stamp_buf, 8 * 32 * 1024);
     a.stamps = stamp_buf;
 #endif
     const size_t lds = resident_lds_bytes(A, T);
@@ -629,7 +645,7 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
         static int shown = 0;
         if (shown++ == 3) {
             (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h((size_t)G * 16);
+            std::vector<unsigned long long> h((size_t)G * 32);
             (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
             const char *nm[6] = {"dots+publish", "all-to-all", "scalars", "maxpy+z", "spmv(own)", "barrier"};
             for (int which = 0; which < 2; ++which) {
@@ -637,13 +653,22 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
                 for (int ph = 0; ph < 6; ++ph) {
                     double sum = 0, mx = 0;
                     for (int g = 0; g < G; ++g) {
-                        const double dt = (double)(h[((size_t)g * 2 + which) * 8 + ph + 1] - h[((size_t)g * 2 + which) * 8 + ph]) / 100.0;
+                        const double dt = (double)(h[((size_t)g * 2 + which) * 16 + ph + 1] - h[((size_t)g * 2 + which) * 16 + ph]) / 100.0;
                         sum += dt; mx = dt > mx ? dt : mx;
                     }
                     fprintf(stderr, "  %s %.2f (max %.2f)", nm[ph], sum / G, mx);
                 }
+                {
+                    double d[4] = {0, 0, 0, 0};
+                    for (int g = 0; g < G; ++g) {
+                        const unsigned long long *q = &h[((size_t)g * 2 + which) * 16];
+                        d[0] += (double)(q[8] - q[0]) / 100.0; d[1] += (double)(q[9] - q[8]) / 100.0;
+                        d[2] += (double)(q[10] - q[9]) / 100.0; d[3] += (double)(q[11] - q[10]) / 100.0;
+                    }
+                    fprintf(stderr, "  || pass 0: writes %.2f barrier %.2f reduce+publish %.2f barrier %.2f", d[0] / G, d[1] / G, d[2] / G, d[3] / G);
+                }
                 unsigned long long lo = ~0ull, hi = 0;
-                for (int g = 0; g < G; ++g) { lo = std::min(lo, h[((size_t)g * 2 + which) * 8]); hi = std::max(hi, h[((size_t)g * 2 + which) * 8]); }
+                for (int g = 0; g < G; ++g) { lo = std::min(lo, h[((size_t)g * 2 + which) * 16]); hi = std::max(hi, h[((size_t)g * 2 + which) * 16]); }
                 fprintf(stderr, "  | entry skew %.2f\n", (double)(hi - lo) / 100.0);
             }
         }

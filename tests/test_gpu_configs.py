@@ -211,6 +211,93 @@ def test_config5_slab_256x256x32_properties(spk, oracle):
     assert np.array_equal(z, zo)                                        # FP32 sweeps: same float operations
 
 
+def test_config5_full_size_256_cubed_as_eight_z_slabs(spk, oracle):
+    """BASELINE config 5 at its REAL size: the 256^3 node grid (50 331 648 rows, 4.05 G stored non-zeros -- beyond int32
+    in total, 0.5 G per rank) as eight z-slabs of 256 x 256 x 32, the decomposition of the 8-GPU run
+    (/root/reference/src/Discretization.c:17: PETSC_DECIDE over 8 ranks), here as eight logical ranks of one process on
+    one GPU (~15 GB of HBM each).  Jacobi with three FP32 inner sweeps, 35 iterations.  Checked: the halo plan (one
+    256 x 256 node plane = 196 608 doubles = 1.57 MB per side), every slab's product INCLUDING its ghost planes against
+    the oracle's CSR loop on the same rows (bitwise away from the cuts, 1e-13 on the two planes next to a cut whose rows add
+    their off-rank columns last), identical histories on all ranks, and the true residual of the iterate (recomputed by
+    the oracle slab by slab) = the device's recurrence."""
+    M, P = 256, 8
+    n = 3 * M ** 3
+    plane = 3 * M * M
+    xin = np.sin(0.37 * np.arange(n))
+    grp = spk.LocalGroup(P)
+    out, errs = [None] * P, []
+    lock = threading.Lock()
+
+    def work(r):
+        try:
+            b, e = spk.partition_slab3d(M, M, M, r, P)
+            A, f = spk.AssembleOperator_Laplace3D(M, M, M, b, e, nthreads=2)
+            assert A.nrows == plane * 32 and A.nnz < 2 ** 31
+            with lock:                                   # (one oracle product at a time: each uses every core)
+                y_ref = oracle.spmv(A, xin)
+            c = spk.Context(0)
+            c.comm_init_local(grp, r)
+            c.set_block(spk.BLOCK_A00, A)
+            fmt = c.spmv_info()["format"]
+            c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.8)
+            y = c.mult(xin[b:e])
+            x, info = c.fgmres(f, rtol=0.0, abstol=0.0, max_it=35)
+            sz = c.sizes()
+            c.close()
+            out[r] = dict(b=b, e=e, y=y, y_ref=y_ref, x=x, info=info, sz=sz, fmt=fmt, f=f, A=A)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            raise
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    grp.close()
+    assert not errs, errs
+    x = np.concatenate([o["x"] for o in out])
+    r2 = 0.0
+    for r, o in enumerate(out):
+        assert o["e"] - o["b"] == plane * 32 and o["fmt"] == "dict3x3"
+        assert o["sz"]["n_ghost"] == plane * ((r > 0) + (r < P - 1))       # one node plane (1.57 MB) per neighbour
+        assert o["info"]["its"] == 35 and o["info"]["reason"] == -3
+        assert np.array_equal(o["info"]["history"], out[0]["info"]["history"])   # every rank takes the same branches
+        cut = np.zeros(o["e"] - o["b"], bool)
+        if r > 0:
+            cut[:plane] = True
+        if r < P - 1:
+            cut[-plane:] = True
+        assert np.array_equal(o["y"][~cut], o["y_ref"][~cut])
+        assert np.allclose(o["y"][cut], o["y_ref"][cut], rtol=1e-13, atol=1e-16)
+        r2 += float(np.sum((o["f"] - oracle.spmv(o["A"], x)) ** 2))   # true residual, slab by slab, by the oracle
+    assert np.sqrt(r2) == pytest.approx(out[0]["info"]["rnorm"], rel=1e-6)
+    assert np.all(np.diff(out[0]["info"]["history"][:31]) <= 1e-14)      # monotone inside a cycle
+
+
+def test_config5_real_size_plane_across_processes(spk, oracle, tmp_path):
+    """The 256 x 256 node plane of config 5 (196 608 doubles = 1.57 MB per side) crossing REAL HIP-IPC windows: two
+    processes with a 256 x 256 x 8 slab each, peer-store backend, bulk halo form; product against the oracle (bitwise
+    away from the cut), identical histories, true residual = recurrence."""
+    grid = (256, 256, 16)
+    prm = dict(dim=3, grid=list(grid), saddle=False, inner=3, solves={"fp32": dict(rtol=0.0, abstol=0.0, max_it=35)})
+    R, info = _launch_slab_worker(tmp_path, 2, prm, 29719, timeout=900)
+    A, f = spk.AssembleOperator_Laplace3D(*grid, nthreads=16)
+    n = A.nrows
+    y_ref = oracle.spmv(A, np.sin(0.37 * np.arange(n)))
+    y = np.zeros(n); x = np.zeros(n); kx = np.zeros(n)
+    for r in range(2):
+        b, e = R[r]["range"]
+        y[b:e], x[b:e], kx[b:e] = R[r]["y"], R[r]["fp32/x"], R[r]["fp32/kx"]
+        assert info[r]["backend"] == "peer-store" and info[r]["halo"] == "bulk" and info[r]["halo_exchanges"]["inner"] == 0
+        assert np.array_equal(R[r]["fp32/hist"], R[0]["fp32/hist"]) and R[r]["fp32/meta"][0] == 35
+    plane = 3 * grid[0] * grid[1]
+    cut = int(R[0]["range"][1])
+    away = np.ones(n, bool)
+    away[cut - plane:cut + plane] = False
+    assert np.array_equal(y[away], y_ref[away]) and relerr(y, y_ref) < KERNEL_TOL
+    assert np.linalg.norm(f - kx) == pytest.approx(float(R[0]["fp32/rnorm"][0]), rel=1e-6)
+    assert np.linalg.norm(f - oracle.spmv(A, x)) == pytest.approx(float(R[0]["fp32/rnorm"][0]), rel=1e-6)
+
+
 # --------------------------------------------------------------------------- execution failures are errors
 def test_reduction_timeout_is_an_execution_error(spk, oracle):
     """A cross-workgroup reduction whose partial never arrives must come back as SPK_ERR_HIP (-2), not

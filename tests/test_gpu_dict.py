@@ -207,3 +207,17 @@ def test_constraint_block_column_validation(spk):
             assert ei.value.code == -1   # SPK_ERR_ARG
             x1, i1 = c.fgmres(rhs, rtol=1e-8)
             assert i1["its"] == i0["its"] and np.array_equal(x1, x0)
+
+
+@pytest.mark.parametrize("order", ["spk_first", "torch_first"])
+def test_context_and_torch_share_one_hip_runtime(spk, order):
+    """a context AND a torch CUDA tensor in one process, the package imported before or after torch (bench.py's N > 1 flow
+    needs both; the import order used to decide whether the second runtime found the GPU)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imp = "import saddle_point_petsc_amd as S, torch" if order == "spk_first" else "import torch, saddle_point_petsc_amd as S"
+    code = imp + "; c = S.Context(0); t = torch.ones(4, device='cuda'); print(float(t.sum())); c.close()"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("4.0"), out.stdout + out.stderr

@@ -340,3 +340,16 @@ def test_bench_byte_model_counts_the_iterations_actually_timed():
     assert bench.solve_bytes(n, nnz, nnzB, 30, 35, p, m, None, True) == full
     # per-iteration average grows with the basis: 20 steps of one cycle move fewer bytes per step than 30
     assert bench.solve_bytes(n, nnz, nnzB, 30, 20, p, m) / 20 < bench.solve_bytes(n, nnz, nnzB, 30, 30, p, m) / 30
+
+
+@pytest.mark.parametrize("order", ["spk_first", "torch_first"])
+def test_one_hip_runtime_whatever_the_import_order(order):
+    """`import saddle_point_petsc_amd` before `import torch` used to map two HIP runtimes into the process (the wheel's
+    private libamdhip64 and /opt/rocm's), and the second found no device.  The package now maps the wheel's copy itself
+    before libspk.so: one runtime in either order (a GPU test creates a context in both orders)."""
+    import subprocess
+    import sys
+    code = ("import saddle_point_petsc_amd as S, torch" if order == "spk_first" else "import torch, saddle_point_petsc_amd as S") + \
+           "; from saddle_point_petsc_amd import _lib; r = _lib.hip_runtimes_mapped(); print(len(r)); assert len(r) == 1, r"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
