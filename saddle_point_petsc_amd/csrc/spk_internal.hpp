@@ -764,6 +764,10 @@ struct spk_ctx {
 
     // preconditioner
     int pc_type = SPK_PC_NONE, schur_fact = SPK_SCHUR_FULL;
+    // agreed over the ranks at KSPSetUp: every rank's local size is even / non-zero.  The head-kernel paths need an even
+    // local size, and all ranks must take the SAME path (their collective sequences differ): decided collectively, not
+    // from rank-local facts
+    bool even_all = false, nonempty_all = false;
     bool pc_ready = false;
     spk::DevBuf<double> dinv, shat, gram;  // n_local, m, m*m
     spk::DevBuf<double> bd;                // the m rows of B D as dense vectors of stride ld (fused Schur path)

@@ -926,6 +926,17 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     hipStream_t s = c->stream;
     c->ensure_scratch();
     c->ensure_vectors();
+    {   // which iteration path the solve takes must not depend on one rank's slab (KSPSetUp is collective)
+        const int P = c->comm->size();
+        const int32_t mine = (c->n_local % 2 == 0 ? 1 : 0) | (c->n_local > 0 ? 2 : 0);
+        std::vector<int32_t> all((size_t)P, mine);
+        if (P > 1) c->comm->host_allgather(&mine, all.data(), sizeof mine);
+        c->even_all = c->nonempty_all = true;
+        for (int32_t v : all) {
+            c->even_all = c->even_all && (v & 1);
+            c->nonempty_all = c->nonempty_all && (v & 2);
+        }
+    }
     c->dinv.alloc((size_t)c->n_local, 8);
     k::extract_diag_inv(c->Ad, c->dinv.p, s);
     const int m = c->m;
@@ -1002,7 +1013,7 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     // dense rows of B D for the fused path (Schur LOWER/FULL, even local size)
     c->bd.release();
     if (pc_type == SPK_PC_SCHUR && m > 0 && !c->b_general && (schur_fact == SPK_SCHUR_FULL || schur_fact == SPK_SCHUR_LOWER) &&
-        c->n_local % 2 == 0 && c->inner_sweeps == 0) {
+        c->even_all && c->inner_sweeps == 0) {
         c->bd.alloc((size_t)c->ld * m, 16);
         k::build_bd(c->Bt, c->dinv.p, m, c->ld, c->bd.p, s);
         // rows 2q / 2q+1 on even / odd entries (x / y degrees of freedom): m/2 planes instead of m rows
@@ -1210,7 +1221,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     const int32_t nl = c->n_local;
     // the same head kernel without a constraint block: Jacobi on K = A (the reference as written,
     // SaddlePointProblem.c:66, and BASELINE config 2): VecScale + PCApply_Jacobi + deferred Givens
-    const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && nl % 2 == 0 && nl > 0 &&
+    const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && c->even_all && c->nonempty_all &&
                         c->inner_sweeps == 0 && !big;
     const bool head = fused || fusedj;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration

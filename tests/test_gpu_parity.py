@@ -7,6 +7,8 @@ Tolerances (FP64, stated per SURVEY.md section 8(c)):
   solution parity  <= 1e-8 relative when both solves run to rtol 1e-10
   iteration parity same count +-1, residual history within 1e-6 relative
 """
+import threading
+
 import numpy as np
 import pytest
 
@@ -624,6 +626,61 @@ def test_fgmres_general_matrix_odd_sizes(spk, oracle, n, m):
     assert relerr(x, xo) < 1e-8
     Kx = oracle.apply_K(Ao, Bo, x) if m else oracle.spmv(Ao, x)
     assert np.linalg.norm(rhs - Kx) <= 2e-10 * np.linalg.norm(rhs)
+
+
+def test_iteration_path_is_agreed_over_the_ranks(spk, oracle):
+    """Two logical ranks, one with an ODD number of rows (501 | 500 of a general 1001-row operator): the head-kernel
+    paths need an even local size, and the ranks' collective sequences differ between paths -- so the path is agreed at
+    KSPSetUp (an all-gather of the local facts), not chosen per rank.  Before, rank 1 took the Jacobi head path and
+    rank 0 the step-by-step one: mismatched all-reduces.  Result against the single-rank solve and the oracle."""
+    n = 1001
+    rng = np.random.default_rng(77)
+    lens = rng.integers(2, 9, n)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    colidx = np.empty(rowptr[-1], np.int32)
+    val = np.empty(rowptr[-1])
+    for i in range(n):
+        k0, k1 = rowptr[i], rowptr[i + 1]
+        cols = np.sort(np.unique(np.concatenate([rng.choice(n, k1 - k0 - 1, replace=False), [i]])))[:k1 - k0]
+        if i not in cols:
+            cols[-1] = i
+            cols = np.sort(cols)
+        cols = np.pad(cols, (0, k1 - k0 - len(cols)), mode="edge")
+        colidx[k0:k1] = cols
+        v = rng.standard_normal(k1 - k0) * 0.3
+        v[cols == i] = 0.0
+        v[np.argmax(cols == i)] = 4.0 + np.abs(v).sum()
+        val[k0:k1] = v
+    rhs = rng.standard_normal(n)
+    Ao = oracle.CSR(rowptr, colidx, val, n)
+    xo, io = oracle.fgmres(Ao, rhs, pc_type=oracle.PC_JACOBI, rtol=1e-10, max_it=2000)
+    cuts = [0, 501, n]
+    grp = spk.LocalGroup(2)
+    out, errs = [None, None], []
+
+    def work(r):
+        try:
+            b, e = cuts[r], cuts[r + 1]
+            k0, k1 = rowptr[b], rowptr[e]
+            Ar = spk.CSR((rowptr[b:e + 1] - k0).astype(np.int32), colidx[k0:k1], val[k0:k1], n, row_begin=b)
+            with spk.Context(0) as c:
+                c.comm_init_local(grp, r)
+                c.set_block(spk.BLOCK_A00, Ar)
+                c.pc_setup(spk.PC_JACOBI, 0)
+                x, info = c.fgmres(rhs[b:e], rtol=1e-10, max_it=2000)
+                out[r] = (x, info, c.iteration_form()[0])
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            raise
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    grp.close()
+    assert not errs and all(not t.is_alive() for t in th), errs
+    assert out[0][2] == out[1][2] == -1                                   # both on the step-by-step path
+    assert np.array_equal(out[0][1]["history"], out[1][1]["history"])
+    assert out[0][1]["reason"] == io["reason"] == 2 and abs(out[0][1]["its"] - io["its"]) <= 2
+    assert relerr(np.concatenate([out[0][0], out[1][0]]), xo) < 1e-8
 
 
 def test_device_resident_vectors(spk, oracle):
