@@ -329,6 +329,12 @@ int spk_time_kernel(spk_ctx *ctx, const char *which, int nv, int warmup, int rep
  * re-arms its reduction buffer and stays usable. */
 int spk_debug_finish_timeout(spk_ctx *ctx, int timeout_ms);
 
+/* Test hook: the bound of every device-side wait for another workgroup's data (cross-workgroup reductions, the resident
+ * cycle kernel's exchanges) in 100 MHz ticks; 0 restores the default (4 s).  A bound of one tick makes the next solve fail
+ * in the MIDDLE of a cycle with SPK_ERR_HIP -- what a lost workgroup would cause -- so that tests can check that the context
+ * stays usable afterwards. */
+int spk_debug_set_wait_bound(spk_ctx *ctx, uint32_t ticks);
+
 /* ---- host-only helpers: row-slab partition and halo plan ------------------ */
 /* (callable without a GPU; used by the multi-rank CPU tests) */
 /* Rows owned by `rank` of `nranks` when `nlines` grid lines of `line_rows`

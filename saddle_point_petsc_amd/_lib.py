@@ -136,6 +136,7 @@ def _load():
     L.spk_comm_get_info.argtypes = [vp, C.POINTER(CommInfo)]
     L.spk_debug_peer_allreduce_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_int, f64p, f64p]
     L.spk_debug_finish_timeout.argtypes = [vp, C.c_int]
+    L.spk_debug_set_wait_bound.argtypes = [vp, C.c_uint32]
     L.spk_set_block.argtypes = [vp, C.c_int, i64, i32, i64, i32p, i32p, f64p]
     L.spk_pc_setup.argtypes = [vp, C.c_int, C.c_int]
     L.spk_pc_set_inner.argtypes = [vp, C.c_int, C.c_double]

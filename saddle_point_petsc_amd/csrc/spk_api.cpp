@@ -432,6 +432,13 @@ int spk_debug_finish_timeout(spk_ctx *c, int timeout_ms)
     SPK_CATCH(c)
 }
 
+int spk_debug_set_wait_bound(spk_ctx *c, uint32_t ticks)
+{
+    if (!c) return SPK_ERR_ARG;
+    c->fin_ticks = ticks ? ticks : 400000000u;
+    return SPK_OK;
+}
+
 int spk_vec_create(spk_ctx *c, int64_t n, double **dev)
 {
     SPK_TRY(c)

@@ -161,6 +161,10 @@ class Context:
         """Test hook: a reduction with a partial that never arrives; raises SpkError (SPK_ERR_HIP)."""
         self._chk(lib.spk_debug_finish_timeout(self.h, timeout_ms))
 
+    def debug_set_wait_bound(self, ticks=0):
+        """Test hook: bound of the device-side waits in 100 MHz ticks (0: the default, 4 s)."""
+        self._chk(lib.spk_debug_set_wait_bound(self.h, ticks))
+
     def set_block(self, which, A):
         nrows = A.nrows
         self._chk(lib.spk_set_block(self.h, which, A.row_begin if which == BLOCK_A00 else 0, nrows,

@@ -111,3 +111,26 @@ def test_resident_cycle_nonzero_guess_and_repeated_solves(spk, oracle):
         x4, i4 = c.fgmres(rhs, x0=0.5 * x1, rtol=1e-8, iteration_form=UN3)
     assert i1["its"] == i2["its"] and np.array_equal(i1["history"], i2["history"]) and np.array_equal(x1, x2)
     assert abs(i3["its"] - i4["its"]) <= 1 and relerr(x3, x4) < 1e-6
+
+
+@pytest.mark.parametrize("form", [RES, UN3])
+def test_execution_failure_in_the_middle_of_a_solve_leaves_the_context_usable(spk, oracle, form):
+    """A wait for another workgroup's data that gives up in the MIDDLE of a cycle (bound set to one tick: what a workgroup
+    that was never dispatched would cause) comes back as SPK_ERR_HIP -- never as a numerical reason -- and the next solve on
+    the same context, with the bound restored, reproduces the undisturbed one bit for bit (buffers re-armed, no stale
+    speculative state) and follows the oracle."""
+    A, B, rhs = _system(spk, 256, 256, True)
+    with _ctx(spk, A, B) as c:
+        x0, i0 = c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=45, iteration_form=form)
+        assert c.iteration_form()[0] == form
+        c.debug_set_wait_bound(1)
+        with pytest.raises(spk.SpkError, match="timed out") as ei:
+            c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=45, iteration_form=form)
+        assert ei.value.code == -2
+        c.debug_set_wait_bound(0)
+        x1, i1 = c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=45, iteration_form=form)
+        y = c.mult(rhs)
+    assert i1["its"] == i0["its"] == 45 and np.array_equal(i1["history"], i0["history"]) and np.array_equal(x1, x0)
+    _, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=0.0, abstol=0.0, max_it=45, threads=8)
+    assert np.allclose(i1["history"], io["history"], rtol=1e-6)
+    assert relerr(y, oracle.apply_K(A, B, rhs)) < 1e-13
