@@ -149,12 +149,14 @@ public:
     int size() const override { return n_; }
     void allreduce_sum(double *dev, int count, hipStream_t s) override
     {
+        ++n_ar_calls_;   // (spk_comm_get_info: collectives that went through this backend)
         if (count <= 0) return;
         SPK_NCCL(rccl().AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm_, s));
     }
     void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                   double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override
     {
+        ++n_ex_calls_;   // (spk_comm_get_info: collectives that went through this backend)
         if (peers.empty()) return;
         SPK_NCCL(rccl().GroupStart());
         for (size_t i = 0; i < peers.size(); ++i) {
@@ -208,6 +210,7 @@ public:
     int size() const override { return g_->nranks; }
     void allreduce_sum(double *dev, int count, hipStream_t s) override
     {
+        ++n_ar_calls_;   // (spk_comm_get_info: collectives that went through this backend)
         if (count <= 0) return;
         for (int off = 0; off < count; off += 256) {  // slots of 256 values per rank: longer payloads in pieces
             const int cnt = std::min(256, count - off);
@@ -223,6 +226,7 @@ public:
     void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                   double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override
     {
+        ++n_ex_calls_;   // (spk_comm_get_info: collectives that went through this backend)
         g_->sendbuf[(size_t)rank_] = sendbuf;
         g_->peers[(size_t)rank_] = peers;
         g_->send_off[(size_t)rank_] = send_off;
@@ -273,6 +277,7 @@ public:
     int size() const override { return n_; }
     void allreduce_sum(double *dev, int count, hipStream_t s) override
     {
+        ++n_ar_calls_;   // (spk_comm_get_info: collectives that went through this backend)
         if (count <= 0) return;
         std::vector<double> h((size_t)count);
         SPK_HIP(hipMemcpyAsync(h.data(), dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
@@ -284,6 +289,7 @@ public:
     void exchange(const double *sendbuf, const std::vector<int> &peers, const std::vector<int64_t> &send_off,
                   double *recvbuf, const std::vector<int64_t> &recv_off, hipStream_t s) override
     {
+        ++n_ex_calls_;   // (spk_comm_get_info: collectives that went through this backend)
         if (peers.empty()) return;
         const int64_t ns = send_off.back(), nr = recv_off.back();
         std::vector<double> hs((size_t)std::max<int64_t>(ns, 1)), hr((size_t)std::max<int64_t>(nr, 1));

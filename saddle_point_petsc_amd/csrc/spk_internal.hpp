@@ -238,8 +238,13 @@ public:
     // window set for the next all-reduce of `count` values, or P == 0 when the backend cannot
     // (the caller then calls allreduce_sum after the kernel)
     virtual k::PeerAR fused_allreduce(int count, int kind = k::kStatArOther) { (void)count; (void)kind; return k::PeerAR{}; }
-    // what the first multi-GPU run needs to be diagnosable from its own output (spk_comm_get_info)
-    virtual void info(spk_comm_info *out) { (void)out; }
+    // what the first multi-GPU run needs to be diagnosable from its own output (spk_comm_get_info): a plain backend
+    // reports how many all-reduces / halo exchanges it carried; the peer-store wrapper overrides with its own split
+    virtual void info(spk_comm_info *out)
+    {
+        out->n_allreduce_inner = n_ar_calls_;
+        out->n_halo_inner = n_ex_calls_;
+    }
     // halo exchange performed INSIDE the kernel that produces the vector (contiguous send ranges
     // only): fills the peer fields of sr for the next exchange and returns true, or returns false
     // (the caller then calls exchange())
@@ -268,6 +273,7 @@ public:
     }
 protected:
     static void memcpy_self(const void *in, void *out, size_t b);
+    int64_t n_ar_calls_ = 0, n_ex_calls_ = 0;
 };
 Comm *make_self_comm();
 Comm *make_rccl_comm(int rank, int nranks, const void *id128, int device);

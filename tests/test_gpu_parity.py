@@ -1173,3 +1173,28 @@ def test_bench_multi_process_flow_over_gloo(spk):
     d3 = last_json(off.stdout)
     assert d3["config"]["collectives"] == "host-callback"
     assert d3["residual_after_steps"] == d2["residual_after_steps"]      # same sums, same order, same bits
+
+
+def test_bench_inner_backend_rehearsal_four_processes_at_1024(spk):
+    """The fallback route of the 8-GPU job, rehearsed at the bench's own size: bench.py --grid 1024 over FOUR processes with
+    the peer-store backend switched off (SPK_BENCH_PEER=0), so that every Krylov all-reduce and every halo exchange goes
+    through the INNER communicator's call sites in spk_comm.cpp (allreduce_sum / exchange: the ones ncclAllReduce and
+    the grouped ncclSend / ncclRecv sit behind on a multi-GPU node; here the host-callback transport over gloo, because RCCL
+    refuses two ranks on one device).  The line must carry its own integrity proof (residual_check) and say which route
+    the collectives took (ranks[])."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPK_BENCH_COMM="gloo", SPK_BENCH_PEER="0")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                          "--master-addr", "127.0.0.1", "--master-port", "29637", os.path.join(root, "bench.py"),
+                          "--gpus", "4", "--grid", "1024", "--steps", "35", "--warmup", "3", "--no-cpu-baseline", "--spmv-reps", "5"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["steps"] == 35 and d["value"] is not None
+    assert d["residual_check"]["consistent"] and d["config"]["collectives"] == "host-callback"
+    assert len(d["ranks"]) == 4
+    for r, info in enumerate(d["ranks"]):
+        assert info["rank"] == r and not info["peer_enabled"] and info["backend"] == "host-callback"
+        assert info["allreduce"]["inner"] >= 2 * 35 and info["allreduce"]["fused"] == 0
+        assert info["halo_exchanges"]["inner"] >= 35
