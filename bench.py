@@ -126,6 +126,11 @@ def main():
     ap.add_argument("--grid-z", type=int, default=0, help="--dim 3: node planes in z (default: --grid); e.g. --grid 256 --grid-z 32 "
                                                           "is one rank's z-slab of the 256^3 grid split 8 ways")
     ap.add_argument("--pc", default="schur-full", choices=["schur-full", "schur-lower", "schur-upper", "schur-diag", "jacobi"])
+    ap.add_argument("--constraints", default="moments", choices=["moments", "div3d"],
+                    help="the (1,0) block of the saddle system: the reference's few long rows (component means and moments: "
+                         "4 rows in 2-D, 6 in 3-D; the fused Schur path), or -- with --dim 3 -- the discrete divergence block in "
+                         "the manner of PETSc's ksp/ex42 (one row per hexahedron: a GENERAL sparse block, which runs PCApply and "
+                         "MatMult step by step)")
     ap.add_argument("--restart", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="bound on the CPU baseline sample")
@@ -203,7 +208,13 @@ def main():
         nnz_global = 9 * (3 * M - 2) * (3 * My - 2) * (3 * Mz - 2)
         rb, re_ = S.partition_slab3d(M, My, Mz, rank, world)
         A, f = S.AssembleOperator_Laplace3D(M, My, Mz, rb, re_, nthreads=asm_threads)
-        if saddle:
+        if saddle and args.constraints == "div3d":
+            # six long mean / moment rows + one divergence row per hexahedron (tests/test_gpu_general_b.py): with Dirichlet
+            # data on every face the divergence rows carry the constant-pressure mode, so g = 0 on them (consistent system)
+            Bm, g6 = S.AssembleOperator_Constraints3D(M, My, Mz, rb, re_)
+            Bd = S.AssembleOperator_Divergence3D(M, My, Mz, rb, re_)
+            B, g = S.CSR.vstack([Bm, Bd]), np.concatenate([g6, np.zeros(Bd.nrows)])
+        elif saddle:
             B, g = S.AssembleOperator_Constraints3D(M, My, Mz, rb, re_)
     else:
         n, nnz_global = S.grid_sizes(M, My)
@@ -393,6 +404,7 @@ def main():
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (B.nrows if saddle else 0), "dim": args.dim, "pc": args.pc, "restart": args.restart,
                    "inner_fp32_sweeps": args.inner_sweeps, "iteration_form": args.iter_form, "iteration_form_run": form_run,
+                   "constraints": args.constraints if saddle else None,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",

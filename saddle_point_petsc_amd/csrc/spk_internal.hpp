@@ -497,8 +497,9 @@ void jacobi(const double *dinv, const double *x, double *y, int64_t n, const int
 void extract_diag_inv(const CsrDev &A, double *dinv, hipStream_t s);
 // y0 = dinv .* (x0 - Bt y1)            (mode 0, UPPER)
 // y0 = dinv .* x0 - dinv .* (Bt y1)    (mode 1, FULL third step, recomputing D x0)
+// scratch != nullptr and Bt tiled (general blocks): Bt y1 by the stream kernel into scratch, then the combination
 void bt_update(int mode, const CsrDev &Bt, const double *dinv, const double *x0, const double *y1,
-               double *y0, const int32_t *done, hipStream_t s);
+               double *y0, const int32_t *done, hipStream_t s, double *scratch = nullptr);
 // FP32 inner solve (damped-Jacobi Richardson sweeps on the diagonal block of A)
 void cvt_scale_f32(const double *x, const float *d32, float omega, float *x32, float *y32, int64_t n,
                    const int32_t *done, hipStream_t s);                       // x32 = (float)x ; y32 = omega d32 x32

@@ -898,10 +898,35 @@ __global__ __launch_bounds__(kThreads) void bt_update_kernel(int mode,
         y0[r] = (mode == 0) ? (xv - c) * d : xv * d - c * d;
     }
 }
+// the same with t = Bt y1 already formed (general constraint blocks: the product by the tiled stream kernel)
+__global__ __launch_bounds__(kThreads) void bt_combine_kernel(int mode, int nrows, const double *__restrict__ dinv,
+                                                              const double *__restrict__ x0, const double *__restrict__ t,
+                                                              double *__restrict__ y0, const int32_t *__restrict__ done)
+{
+    if (done && *done) return;
+    for (int r = blockIdx.x * kThreads + threadIdx.x; r < nrows; r += gridDim.x * kThreads) {
+        const double c = t[r];
+        if (mode >= 2) {
+            y0[r] = mode == 2 ? x0[r] - c : c;
+            continue;
+        }
+        const double d = dinv[r], xv = x0[r];
+        y0[r] = (mode == 0) ? (xv - c) * d : xv * d - c * d;
+    }
+}
 void bt_update(int mode, const CsrDev &Bt, const double *dinv, const double *x0, const double *y1,
-               double *y0, const int32_t *done, hipStream_t s)
+               double *y0, const int32_t *done, hipStream_t s, double *scratch)
 {
     if (Bt.nrows == 0) return;
+    if (scratch && Bt.ntiles > 0) {
+        // a block of many short rows (B^T: a handful of entries per row, scattered over the multipliers): one thread per
+        // row reads its entries uncoalesced (measured 344 us on the 96^3 divergence block) -- the tiled stream kernel
+        // streams them (52 us), the combination is one more pass over the vector
+        spmv(Bt, y1, scratch, nullptr, nullptr, done, s);
+        const int grid = std::min((Bt.nrows + kThreads - 1) / kThreads, kMaxBlocks * 4);
+        hipLaunchKernelGGL(bt_combine_kernel, dim3(grid), dim3(kThreads), 0, s, mode, Bt.nrows, dinv, x0, scratch, y0, done);
+        return;
+    }
     const int grid = std::min((Bt.nrows + kThreads - 1) / kThreads, kMaxBlocks * 4);
     hipLaunchKernelGGL(bt_update_kernel, dim3(grid), dim3(kThreads), 0, s, mode, Bt.rowptr.p, Bt.colidx.p,
                        Bt.val.p, Bt.nrows, dinv, x0, y1, y0, done);

@@ -843,11 +843,12 @@ static void set_block_B(spk_ctx *c, int32_t m, int64_t ncols_global, const int32
             }
         });
     }
-    upload_csr(c, c->Bt, nl, m, trp, tci, tv, false);
+    upload_csr(c, c->Bt, nl, m, trp, tci, tv, c->b_general);   // (a general block: tiles for the stream kernel)
     c->m = m;
     c->have_B = m > 0;
     c->pc_ready = false;
     c->ensure_vectors();
+    if (c->b_general && c->tmpb.n < (size_t)c->ld) c->tmpb.alloc((size_t)c->ld);   // scratch of the B^T products (bt_update)
 }
 
 void set_block(spk_ctx *c, int which, int64_t row_begin, int32_t nrows_local, int64_t ncols_global,
@@ -907,7 +908,14 @@ void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool h
     }
     const k::OffDiag od = c->offdiag();
     const k::OffDiag *odp = c->n_ghost > 0 ? &od : nullptr;   // off-rank columns in the same kernel
-    a_mult(c, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, false, odp);
+    if (m > 0 && c->b_general) {
+        // B^T lambda of a general block first (tiled stream kernel), the A block accumulates onto it: the row-by-row
+        // epilogue of the product kernels reads such rows uncoalesced (96^3 divergence block: 474 us against 148 + 52)
+        k::spmv(c->Bt, x + nl, y, nullptr, nullptr, done, s);
+        a_mult(c, x, y, nullptr, nullptr, done, true, odp);
+    } else {
+        a_mult(c, x, y, m > 0 ? &c->Bt : nullptr, x + nl, done, false, odp);
+    }
     if (m > 0) {
         apply_B(c, x, nullptr, y + nl, done);
         c->comm->allreduce_sum(y + nl, m, s);
@@ -1083,7 +1091,7 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
             break;
         case SPK_SCHUR_UPPER:
             k::schur_y1(SPK_SCHUR_UPPER, m, x1, nullptr, c->shat.p, y1, done, s);
-            k::bt_update(2, c->Bt, c->dinv.p, x0, y1, c->tmp.p, done, s);   // x0 - B^T y1
+            k::bt_update(2, c->Bt, c->dinv.p, x0, y1, c->tmp.p, done, s, c->b_general ? c->tmpb.p : nullptr);   // x0 - B^T y1
             inner_apply(c, c->tmp.p, y0, 0, done);
             break;
         default:  // LOWER, FULL
@@ -1092,7 +1100,7 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
             c->comm->allreduce_sum(c->ttmp.p, m, s);
             k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
             if (c->schur_fact == SPK_SCHUR_FULL) {
-                k::bt_update(3, c->Bt, c->dinv.p, x0, y1, c->tmp.p, done, s);   // B^T y1
+                k::bt_update(3, c->Bt, c->dinv.p, x0, y1, c->tmp.p, done, s, c->b_general ? c->tmpb.p : nullptr);   // B^T y1
                 inner_apply(c, c->tmp.p, y0, 1, done);                            // y0 -= A^ ^-1 B^T y1
             }
             break;
@@ -1115,7 +1123,7 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
         break;
     case SPK_SCHUR_UPPER:
         k::schur_y1(SPK_SCHUR_UPPER, m, x1, nullptr, c->shat.p, y1, done, s);
-        k::bt_update(0, c->Bt, c->dinv.p, x0, y1, y0, done, s);
+        k::bt_update(0, c->Bt, c->dinv.p, x0, y1, y0, done, s, c->b_general ? c->tmpb.p : nullptr);
         break;
     case SPK_SCHUR_LOWER:
     default:  // FULL
@@ -1124,7 +1132,7 @@ void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done)
         c->comm->allreduce_sum(c->ttmp.p, m, s);
         k::schur_y1(c->schur_fact, m, x1, c->ttmp.p, c->shat.p, y1, done, s);
         if (c->schur_fact == SPK_SCHUR_LOWER) k::jacobi(c->dinv.p, x0, y0, nl, done, s);
-        else k::bt_update(1, c->Bt, c->dinv.p, x0, y1, y0, done, s);
+        else k::bt_update(1, c->Bt, c->dinv.p, x0, y1, y0, done, s, c->b_general ? c->tmpb.p : nullptr);
         break;
     }
 }
