@@ -11,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=100)
 ap.add_argument("--grid-y", type=int, default=0)
-ap.add_argument("--kernels", default="spmv,spmv_bcsr,mult,pc,wide_dot,bt_update,scale,mdot,maxpy")
+ap.add_argument("--kernels", default="spmv,spmv_bcsr,spmv_dict,mult,pc,wide_dot,bt_update,scale,mdot,maxpy")
 ap.add_argument("--nvs", default="1,8,9,16,17,24,25,30")
 a = ap.parse_args()
 M = a.grid
@@ -22,7 +22,7 @@ n, nnz, nnzB = A.nrows, A.nnz, B.nnz
 c = S.Context(0)
 c.set_block(S.BLOCK_A00, A); c.set_block(S.BLOCK_A10, B); c.pc_setup(S.PC_SCHUR, S.SCHUR_FULL)
 vec = 8 * n
-model = {"spmv": 12 * nnz + 4 * n + 2 * vec, "spmv_bcsr": 12 * nnz + 4 * n + 2 * vec, "mult": 12 * nnz + 4 * n + 2 * vec + 2 * (12 * nnzB) + 4 * n + vec,
+model = {"spmv": 12 * nnz + 4 * n + 2 * vec, "spmv_bcsr": 12 * nnz + 4 * n + 2 * vec, "spmv_dict": 12 * nnz + 4 * n + 2 * vec, "mult": 12 * nnz + 4 * n + 2 * vec + 2 * (12 * nnzB) + 4 * n + vec,
          "pc": (12 * nnzB + 2 * vec) + (12 * nnzB + 4 * n + 3 * vec), "wide_dot": 12 * nnzB + vec,
          "bt_update": 12 * nnzB + 4 * n + 3 * vec, "scale": 2 * vec}
 out = {}
