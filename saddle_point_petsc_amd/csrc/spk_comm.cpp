@@ -667,6 +667,24 @@ public:
         ++n_halo_fused_;
         return true;
     }
+    bool resident_plan(int n_ar, int n_halo, k::PeerAR &ar, k::SendRanges &sr0, k::SendRanges &sr1, double *xghost) override
+    {
+        if (!fuse_ || n_ar < 1) return false;
+        const bool have_halo = !halo_peers_.empty();
+        if (have_halo && (!halo_ok_ || bulk_ || n_halo < 0)) return false;
+        if (have_halo && n_halo > 0) {
+            if (!fused_halo(sr0, xghost)) return false;
+            if (n_halo > 1) {
+                if (!fused_halo(sr1, xghost)) return false;
+                halo_seq_ += (uint32_t)(n_halo - 2);
+                n_halo_fused_ += n_halo - 2;
+            }
+        }
+        ar = next_ar(k::kStatArDots);
+        ar_seq_ += (uint32_t)(n_ar - 1);
+        n_ar_fused_ += n_ar;
+        return true;
+    }
     void check(hipStream_t s) override
     {
         (void)s;

@@ -249,6 +249,12 @@ public:
     // only): fills the peer fields of sr for the next exchange and returns true, or returns false
     // (the caller then calls exchange())
     virtual bool fused_halo(k::SendRanges &sr, double *xghost) { (void)sr; (void)xghost; return false; }
+    // The resident restart-cycle kernel runs a whole cycle's collectives inside ONE launch: n_ar all-reduces and n_halo
+    // halo exchanges with consecutive sequence numbers.  Fills the window set of the first all-reduce and the send ranges
+    // of the first two exchanges (the two staging parities; sr0 / sr1 come in as copies of the context's ranges) and
+    // reserves the numbers; false when this backend cannot (the caller keeps the launch-by-launch form)
+    virtual bool resident_plan(int n_ar, int n_halo, k::PeerAR &ar, k::SendRanges &sr0, k::SendRanges &sr1, double *xghost)
+    { (void)n_ar; (void)n_halo; (void)ar; (void)sr0; (void)sr1; (void)xghost; return false; }
     // throws SPK_ERR_COMM when a device-side wait of this backend has timed out (call after a sync)
     virtual void check(hipStream_t s) { (void)s; }
     virtual const char *name() const { return "self"; }
@@ -685,6 +691,9 @@ struct ResidentArgs {
     double *sc_out;
     int32_t *err;
     uint32_t ticks;
+    PeerAR ar;             // several ranks: Comm::resident_plan (P <= 1: single rank)
+    SendRanges sr0, sr1;
+    OffDiag od;
 };
 bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t *done, hipStream_t s);   // false: shape does not fit
 int64_t resident_scratch_doubles(int num_cus, int mk);
@@ -775,6 +784,7 @@ struct spk_ctx {
     // local size, and all ranks must take the SAME path (their collective sequences differ): decided collectively, not
     // from rank-local facts
     bool even_all = false, nonempty_all = false;
+    bool res_fit_all = false;   // every rank's slab fits the resident restart-cycle kernel
     bool pc_ready = false;
     spk::DevBuf<double> dinv, shat, gram;  // n_local, m, m*m
     spk::DevBuf<double> bd;                // the m rows of B D as dense vectors of stride ld (fused Schur path)

@@ -132,6 +132,12 @@ struct ResArgs {
     double *sc_out;        // scale factors of the un-normalised basis (krylov_cycle_end)
     int32_t *err;
     uint32_t ticks;
+    // several ranks (peer-store backend): the ranks' sums of every exchange go through the all-reduce windows -- the master
+    // workgroup stores this rank's, EVERY workgroup reads all ranks' out of the rank's own window and adds them in rank
+    // order; the halo rows of z~ go as granules into the neighbours' staging, the rows with off-rank columns wait for theirs
+    PeerAR ar;             // P <= 1: single rank; seq = the first all-reduce of this launch
+    SendRanges sr0, sr1;   // the two staging parities; sr0.seq = the first exchange of this launch (n == 0: no neighbours)
+    OffDiag od;            // off-rank columns by local row (colidx = ghost number)
     int tab_bytes;         // LDS bytes of the matrix tables (16-byte multiple)
 #ifdef SPK_RES_STAMPS
     unsigned long long *stamps;   // developer build: 100 MHz time stamps of the phases of iterations 10 and 25, per workgroup
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
     double *prod = reinterpret_cast<double *>(chi + (size_t)a.nwide * T);   // kResPass x LDP; also the all-to-all partials
     double *ws = prod + kResPass * LDP;
     double *dots = ws;                      // 64
-    double *hs = dots + 64;                 // 32: MAXPY coefficients h_i sc_i
+    double *dotsg = dots + 64;              // 64: the same summed over the ranks
+    double *hs = dotsg + 64;                // 32: MAXPY coefficients h_i sc_i
     double *hcolb = hs + 32;                // 2 x 34: Hessenberg column (scaled), by iteration parity
     double *scl = hcolb + 68;               // 34: scale factors
     double *gcc = scl + 34, *gss = gcc + 34, *grs = gss + 34, *gHr = grs + 34;   // rotations, rhs, rotated column
@@ -349,10 +356,46 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             dots[t] = s;
         }
         bar_lds();
+        if (a.ar.P > 1) {
+            // ---- (b') over the ranks: this rank's sums leave ONCE (master workgroup, 8-byte tagged granules into every
+            // rank's window); every workgroup of every rank then finds all P contributions in its rank's OWN window and adds
+            // them in rank order -- the same bits on every workgroup of every rank
+            if (t < 2 * nvt) {
+                const uint32_t seq = a.ar.seq + (uint32_t)loc;
+                const int slot = (int)(seq & (kArSlots - 1));
+                const uint32_t half = reinterpret_cast<const uint32_t *>(dots)[t];
+                if (master) {
+                    const unsigned long long g = ((unsigned long long)seq << 32) | half;
+                    const size_t mine = ((size_t)slot * a.ar.P + a.ar.me) * kArGranules + t;
+                    for (int p = 0; p < a.ar.P; ++p) st_sys(a.ar.win[p] + mine, g);
+                }
+                const unsigned long long *own = a.ar.win[a.ar.me] + (size_t)slot * a.ar.P * kArGranules + t;
+                const unsigned long long tw0 = (a.ar.stats && master && t == 0) ? wall_clock64() : 0ull;
+                double sum = 0.0;
+                bool ok = true;
+                for (int p = 0; p < a.ar.P; ++p) {
+                    uint32_t lo;
+                    ok = granule_wait(own + (size_t)p * kArGranules, seq, a.ar.timeout_ms, lo, a.ar.err) && ok;
+                    const uint32_t other = __shfl_xor(lo, 1, kWave);
+                    sum += join_halves(lo, other);   // meaningful in even lanes
+                }
+                if (a.ar.stats && master && t == 0) {
+                    atomicAdd(a.ar.stats + 2 * kStatArDots, wall_clock64() - tw0);
+                    atomicAdd(a.ar.stats + 2 * kStatArDots + 1, 1ull);
+                }
+                if (!(t & 1)) dotsg[t >> 1] = sum;
+                if (!ok) {
+                    raise_comm_error(a.ar.err, 1 + kStatArDots, seq);
+                    flag[0] = 1;
+                }
+            }
+            bar_lds();
+        }
+        const double *dt = a.ar.P > 1 ? dotsg : dots;
         RES_STAMP(2);
         // ---- (c) scalar work, every workgroup for itself.  Pending of iteration loc - 1: its norm has just arrived, so
         // its Givens step runs now -- in the LAST wave, beside wave 0's work for this iteration
-        const double nrm2 = dots[nvt - 1];
+        const double nrm2 = dt[nvt - 1];
         if (t == TG && !flag[0] && loc > 0) {
             res_givens(*L, loc - 1, hcolb + 34 * ((loc - 1) & 1), nrm2, gcc, gss, grs, gHr);
             flag[1] = loc - 1;
@@ -363,7 +406,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             const int i = t;
             double *hcol = hcolb + 34 * (loc & 1);
             const double sci = i < nv ? (i == loc ? s_w : scl[i]) : 0.0;
-            const double hi = i < nv ? sci * s_w * dots[i] : 0.0;
+            const double hi = i < nv ? sci * s_w * dt[i] : 0.0;
             const double ci = hi * sci;
             if (i == 0) scl[loc] = s_w;
             if (i < nv) {
@@ -392,7 +435,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                 for (int r = 0; r < MM; ++r) {
                     const double tsum0 = __shfl(tsv[r], 0, kWave), lsum0 = __shfl(lsv[r], 0, kWave);
                     if (i == r && r < m) {
-                        tu = dots[nv + r] * s_w - tsum0;   // B D w' = B D w - sum h_i (B D v_i)
+                        tu = dt[nv + r] * s_w - tsum0;   // B D w' = B D w - sum h_i (B D v_i)
                         wraw = s_w * wl[r] - lsum0;
                     }
                 }
@@ -474,6 +517,24 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
         if (active) {   // write-through: the neighbours gather these rows below
             st_agent(Zn + 2 * br, zz.x);
             st_agent(Zn + 2 * br + 1, zz.y);
+            if (a.sr0.n > 0) {   // rows a neighbouring RANK needs: as granules straight into its staging (this exchange's parity)
+                const uint32_t hseq = a.sr0.seq + (uint32_t)loc;
+                const SendRanges &sr = (loc & 1) ? a.sr1 : a.sr0;
+                const unsigned long long tag = (unsigned long long)hseq << 32;
+                for (int q = 0; q < sr.n; ++q) {
+                    const int64_t e0 = 2 * br - sr.r0[q];
+                    if (e0 >= 0 && e0 < sr.len[q]) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(zz.x);
+                        st_sys(sr.remote[q] + 2 * e0, tag | (bits & 0xffffffffull));
+                        st_sys(sr.remote[q] + 2 * e0 + 1, tag | (bits >> 32));
+                    }
+                    if (e0 + 1 >= 0 && e0 + 1 < sr.len[q]) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(zz.y);
+                        st_sys(sr.remote[q] + 2 * e0 + 2, tag | (bits & 0xffffffffull));
+                        st_sys(sr.remote[q] + 2 * e0 + 3, tag | (bits >> 32));
+                    }
+                }
+            }
         }
         bar_lds();   // (ys, w1s read above by everybody; the multiplier entries of the next w~)
         if (t < m) wl[t] = w1s[t];
@@ -534,6 +595,25 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                     }
                 }
             }
+            if (a.od.rowptr) {   // off-rank columns of these two rows: the neighbour ranks' granules (fused multiply-adds, as
+                                 // in the product kernels' epilogue)
+                const uint32_t hseq = a.sr0.seq + (uint32_t)loc;
+                const unsigned long long *mine = ((loc & 1) ? a.sr1 : a.sr0).mine;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    double acc = r ? s1 : s0;
+                    for (int k = a.od.rowptr[2 * br + r]; k < a.od.rowptr[2 * br + r + 1]; ++k) {
+                        const int g = a.od.colidx[k];
+                        uint32_t lo = 0, hi = 0;
+                        const bool ok = granule_wait(mine + 2 * (size_t)g, hseq, a.sr0.timeout_ms, lo, a.sr0.err) &&
+                                        granule_wait(mine + 2 * (size_t)g + 1, hseq, a.sr0.timeout_ms, hi, a.sr0.err);
+                        if (!ok) raise_comm_error(a.sr0.err, 21, hseq);
+                        acc = __builtin_fma(a.od.val[k], join_halves(lo, hi), acc);
+                    }
+                    if (r) s1 = acc;
+                    else s0 = acc;
+                }
+            }
             if (NP > 0) {
                 s0 += cc.x;
                 s1 += cc.y;
@@ -570,18 +650,27 @@ __global__ __launch_bounds__(kThreads) void res_arm_kernel(double *P, int64_t nP
 }
 
 static int res_threads(int rpw) { return rpw <= 256 ? 256 : 512; }
+// workgroups of the launch: one per compute unit.  SPK_RES_WGS caps it (test rigs where several processes share ONE
+// device: their launches must all be resident together, or each waits for workgroups of its own that cannot start)
+static int res_grid_cap(int num_cus)
+{
+    static const int cap = [] { const char *e = getenv("SPK_RES_WGS"); return e ? atoi(e) : 0; }();
+    int g = std::min(num_cus, kResG);
+    if (cap > 0) g = std::min(g, cap);
+    return g;
+}
 size_t resident_lds_bytes(const DictDev &A, int T)
 {
     const size_t tab = ((size_t)A.lds_bytes + 15) & ~(size_t)15;
     const size_t codes = (size_t)(A.kmax + __builtin_popcount(A.wide_mask)) * T * 8;
-    const size_t dbl = (size_t)kResPass * (T + 8) + 64 + 32 + 68 + 34 * 5 + 32 * 8 * 2 + 8 * 6 + 64;
+    const size_t dbl = (size_t)kResPass * (T + 8) + 128 + 32 + 68 + 34 * 5 + 32 * 8 * 2 + 8 * 6 + 64;
     return tab + codes + dbl * sizeof(double) + sizeof(KrylovState) + 64;
 }
 // does the resident cycle kernel take this system?  (np: planes of B D)
 bool resident_fits(const DictDev &A, int num_cus, int mk, int np)
 {
     if (!A.ok || A.bs != 2 || num_cus < 1 || A.nbrows < 1) return false;
-    const int G = (int)std::min<int64_t>(std::min(num_cus, 256), ((int64_t)A.nbrows + 63) / 64);
+    const int G = (int)std::min<int64_t>(res_grid_cap(num_cus), ((int64_t)A.nbrows + 63) / 64);
     const int rpw = (A.nbrows + G - 1) / G;
     if (rpw > 512 || mk > kResMaxV - 1 || mk < 2 || np > 4) return false;
     return resident_lds_bytes(A, res_threads(rpw)) <= 160 * 1024;
@@ -592,7 +681,7 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
 {
     const int np = r.m == 0 ? 0 : (r.packed ? r.m / 2 : r.m);
     if (!resident_fits(A, num_cus, r.mk, np)) return false;
-    const int G = (int)std::min<int64_t>(std::min(num_cus, 256), ((int64_t)A.nbrows + 63) / 64);
+    const int G = (int)std::min<int64_t>(res_grid_cap(num_cus), ((int64_t)A.nbrows + 63) / 64);
     const int rpw = (A.nbrows + G - 1) / G;
     const int T = res_threads(rpw);
     int dummy = 0;
@@ -605,6 +694,7 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
     a.nl = r.nl; a.ld = r.ld;
     a.V0 = r.V0; a.V1 = r.V1; a.Z = r.Z; a.dinv = r.dinv; a.bd = r.bd; a.ldb = r.ldb; a.shat = r.shat; a.gram = r.gram;
     a.P = r.P; a.ka = r.ka; a.sc_out = r.sc_out; a.err = r.err; a.ticks = r.ticks;
+    a.ar = r.ar; a.sr0 = r.sr0; a.sr1 = r.sr1; a.od = r.od;
     a.tab_bytes = (int)(((size_t)A.lds_bytes + 15) & ~(size_t)15);
 #ifdef SPK_RES_STAMPS
     static unsigned long long *stamp_buf = nullptr;

@@ -1042,6 +1042,16 @@ void pc_setup(spk_ctx *c, int pc_type, int schur_fact)
     SPK_HIP(hipStreamSynchronize(s));
     c->pc_type = pc_type;
     c->schur_fact = schur_fact;
+    {   // does EVERY rank's slab fit the resident cycle kernel (restart <= 30)?  agreed here, like the iteration path above
+        const int planes = !c->bd.p ? 0 : (c->bd_packed ? m / 2 : m);
+        const int32_t mine = (c->spmv_format == 1 && c->Adict.ok && c->Adict.bs == 2 && c->n_local % 2 == 0 &&
+                              k::resident_fits(c->Adict, c->num_cus, 30, planes)) ? 1 : 0;
+        const int P = c->comm->size();
+        std::vector<int32_t> all((size_t)P, mine);
+        if (P > 1) c->comm->host_allgather(&mine, all.data(), sizeof mine);
+        c->res_fit_all = true;
+        for (int32_t v : all) c->res_fit_all = c->res_fit_all && v != 0;
+    }
     c->pc_ready = true;
 }
 
@@ -1263,9 +1273,14 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // RESIDENT: one launch per restart cycle, the basis in registers (spk_k_resident.hip): what AUTO takes where it fits
     static const bool res_env_off = [] { const char *e = getenv("SPK_RESIDENT"); return e && !strcmp(e, "0"); }();
     const int res_planes = !fused ? 0 : (bpk ? m / 2 : m);
-    const bool resident = un3 && (form == SPK_ITER_RESIDENT || (form == SPK_ITER_AUTO && !res_env_off)) && c->comm->size() == 1 &&
-                          c->peers.empty() && c->n_ghost == 0 && c->spmv_format == 1 && c->Adict.ok && c->Adict.bs == 2 &&
-                          nl % 2 == 0 && k::resident_fits(c->Adict, c->num_cus, mk, res_planes);
+    // several ranks: every rank must take it (agreed at KSPSetUp: res_fit_all), the collectives must be the peer-store
+    // backend's (they run inside the launch), and the halo rows must be contiguous send ranges
+    const bool res_multi = c->comm->size() > 1;
+    const bool res_rank_ok = !res_multi ? (c->peers.empty() && c->n_ghost == 0)
+                                        : (c->res_fit_all && c->comm->fuses() && (c->peers.empty() || c->send_ranges.n > 0));
+    const bool resident = un3 && (form == SPK_ITER_RESIDENT || (form == SPK_ITER_AUTO && !res_env_off)) && res_rank_ok &&
+                          c->spmv_format == 1 && c->Adict.ok && c->Adict.bs == 2 && nl % 2 == 0 && mk >= (res_multi ? 3 : 2) &&
+                          k::resident_fits(c->Adict, c->num_cus, mk, res_planes);
     if (resident) {
         const size_t need = (size_t)k::resident_scratch_doubles(c->num_cus, mk);
         if (c->res_P.n < need) c->res_P.alloc(need);
@@ -1394,6 +1409,17 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     r.V0 = Vj(0); r.V1 = Vj(1); r.Z = Z; r.dinv = c->dinv.p; r.bd = bdp; r.ldb = ld;
                     r.shat = c->shat.p; r.gram = c->gram.p; r.P = c->res_P.p; r.ka = c->ka; r.sc_out = c->ba_sc.p;
                     r.err = c->errw.p; r.ticks = c->fin_ticks;
+                    r.sr0 = k::SendRanges{};
+                    r.sr1 = k::SendRanges{};
+                    if (res_multi) {
+                        // the launch's mk + 1 all-reduces and mk - 1 halo exchanges: consecutive sequence numbers, reserved now
+                        r.sr0 = c->send_ranges;
+                        r.sr1 = c->send_ranges;
+                        if (!c->comm->resident_plan(mk + 1, c->peers.empty() ? 0 : mk - 1, r.ar, r.sr0, r.sr1, c->xghost.p))
+                            fail(SPK_ERR_COMM, "fgmres: the communicator cannot carry a resident cycle (agreed at set-up, refused now)");
+                        if (c->peers.empty()) r.sr0.n = r.sr1.n = 0;
+                        if (c->n_ghost > 0) r.od = c->offdiag();
+                    }
                     if (!k::cycle_resident(c->Adict, c->num_cus, r, done, s)) fail(SPK_ERR_STATE, "fgmres: resident cycle kernel refused its shape");
                     break;
                 }

@@ -68,6 +68,42 @@ def main():
         dist.destroy_process_group()
         return
 
+    if mode == "resident":
+        # the resident restart-cycle kernel (iteration form 6) ACROSS RANKS: the ranks' inner products through the all-reduce
+        # windows inside the launch, the halo rows of z~ as granules between the edge workgroups.  SPK_RES_WGS (set by the
+        # test) caps every process's grid so that all processes' launches are resident on the one device together.
+        for name, grid, pc, fact, kw in (("schur_full", (96, 64), S.PC_SCHUR, S.SCHUR_FULL, dict(rtol=1e-9, max_it=900)),
+                                         ("schur_lower", (96, 64), S.PC_SCHUR, S.SCHUR_LOWER, dict(rtol=0.0, abstol=0.0, max_it=75)),
+                                         ("jacobi", (128, 100), S.PC_JACOBI, 0, dict(rtol=0.0, abstol=0.0, max_it=95)),
+                                         ("jacobi_r7", (40, 36), S.PC_JACOBI, 0, dict(rtol=1e-7, restart=7, max_it=4000))):
+            saddle = pc == S.PC_SCHUR
+            mx, my = grid
+            b, e = S.partition_slab(mx, my, rank, world)
+            A, f = S.AssembleOperator_Laplace(mx, my, b, e)
+            Bs, g = S.AssembleOperator_Constraints(mx, my, b, e) if saddle else (None, np.zeros(0))
+            rhs = np.concatenate([f, g])
+            c = S.Context(0)
+            c.comm_init_torch(dist, rank, world)
+            assert c.comm_enable_peer(), c.last_error()
+            c.set_block(S.BLOCK_A00, A)
+            if saddle:
+                c.set_block(S.BLOCK_A10, Bs)
+            c.pc_setup(pc, fact)
+            for form in (6, 5):
+                x, info = c.fgmres(rhs, iteration_form=form, **kw)
+                k = f"{name}/{form}/"
+                res[k + "x"], res[k + "hist"] = x, info["history"]
+                res[k + "kx"] = c.mult(x)
+                res[k + "meta"] = np.array([b, e, info["its"], info["reason"], c.iteration_form()[0]], np.int64)
+                res[k + "rnorm"] = np.array([info["rnorm"]])
+            ci = c.comm_info()
+            res[name + "/fused"] = np.array([ci["allreduce"]["fused"], ci["halo_exchanges"]["fused"], ci["allreduce"]["inner"]], np.int64)
+            c.close()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     # (name, dim, grid, pc, fact, inner sweeps, fused); solver options by name suffix, see OPTS
     OPTS = {"single": dict(single_reduce=1), "mgs": dict(orthog=1), "refine": dict(cgs_refine=1),
             "r62": dict(restart=62), "guess": dict()}
@@ -111,7 +147,9 @@ def main():
             z = c.pc_apply(xin)
             okw = OPTS.get(name.rsplit("_", 1)[-1], {})
             x0 = 0.01 * xin if name.endswith("_guess") else None          # -ksp_initial_guess_nonzero
-            x, info = c.fgmres(rhs, x0=x0, rtol=1e-9, fused=fused, **okw)
+            # (form 5 in both runs: with the peer-store backend AUTO would take the resident form 6, which the host-staged
+            # run this one is compared with bit for bit cannot)
+            x, info = c.fgmres(rhs, x0=x0, rtol=1e-9, fused=fused, iteration_form=5, **okw)
             k = f"{name}/{peer}/"
             res[k + "y"], res[k + "z"], res[k + "x"] = y, z, x
             res[k + "hist"] = info["history"]

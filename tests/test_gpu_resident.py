@@ -134,3 +134,53 @@ def test_execution_failure_in_the_middle_of_a_solve_leaves_the_context_usable(sp
     _, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, rtol=0.0, abstol=0.0, max_it=45, threads=8)
     assert np.allclose(i1["history"], io["history"], rtol=1e-6)
     assert relerr(y, oracle.apply_K(A, B, rhs)) < 1e-13
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_resident_cycle_across_ranks(spk, oracle, tmp_path, P):
+    """Form 6 over P PROCESSES (peer-store backend over real HIP-IPC windows; tests/_peer_worker.py, mode "resident"): inside
+    the one launch per cycle the ranks' inner products cross the all-reduce windows and the halo rows of z~ go as granules
+    from edge workgroup to edge workgroup.  Every rank holds the same history bit for bit, form 6 agrees with form 5 on the
+    same context (1e-9 over the first cycle), both follow the oracle, the true residual (device products) equals the
+    recurrence, and no collective left the in-kernel route.  SPK_RES_WGS caps each process's grid: all processes share one
+    device here, and their launches must be resident together."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPK_RES_WGS=str(240 // P))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(P),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29680 + P),
+                          os.path.join(root, "tests", "_peer_worker.py"), str(tmp_path), "resident"],
+                         capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    R = [np.load(tmp_path / f"rank{r}.npz") for r in range(P)]
+    for name, grid, saddle, fact, okw in (("schur_full", (96, 64), True, 3, dict(rtol=1e-9, max_it=900)),
+                                          ("schur_lower", (96, 64), True, 1, dict(rtol=0.0, abstol=0.0, max_it=75)),
+                                          ("jacobi", (128, 100), False, 0, dict(rtol=0.0, abstol=0.0, max_it=95)),
+                                          ("jacobi_r7", (40, 36), False, 0, dict(rtol=1e-7, restart=7, max_it=4000))):
+        A, B, rhs = _system(spk, grid[0], grid[1], saddle)
+        n, m = A.nrows, (B.nrows if saddle else 0)
+        kw = dict(B=B, pc_type=oracle.PC_SCHUR, schur_fact=fact) if saddle else dict(pc_type=oracle.PC_JACOBI)
+        xo, io = oracle.fgmres(A, rhs, **kw, **okw)
+        for form in (6, 5):
+            x = np.zeros(n + m); kx = np.zeros(n + m)
+            for r in range(P):
+                k = f"{name}/{form}/"
+                b, e, its, reason, ran = R[r][k + "meta"]
+                assert ran == form, (name, form, ran)
+                assert np.array_equal(R[r][k + "hist"], R[0][k + "hist"])          # every rank takes the same branches
+                x[b:e], kx[b:e] = R[r][k + "x"][:e - b], R[r][k + "kx"][:e - b]
+                if m:
+                    x[n:], kx[n:] = R[r][k + "x"][-m:], R[r][k + "kx"][-m:]
+                    assert np.array_equal(R[r][k + "x"][-m:], R[0][k + "x"][-m:])
+                assert reason == io["reason"] and abs(its - io["its"]) <= max(1, io["its"] // 100)
+            h = R[0][f"{name}/{form}/hist"]
+            kk = min(len(h), len(io["history"]), 21)
+            assert np.allclose(h[:kk], io["history"][:kk], rtol=1e-6), (name, form)
+            assert np.linalg.norm(rhs - kx) == pytest.approx(float(R[0][f"{name}/{form}/rnorm"][0]), rel=1e-5, abs=1e-14)
+            if io["reason"] == 2:
+                assert relerr(x, xo) < 1e-6
+        h6, h5 = R[0][f"{name}/6/hist"], R[0][f"{name}/5/hist"]
+        kk = min(len(h6), len(h5), 8 if name == "jacobi_r7" else 31)
+        assert np.allclose(h6[:kk], h5[:kk], rtol=1e-9), name
+        for r in range(P):
+            assert R[r][name + "/fused"][0] > 0 and R[r][name + "/fused"][2] == 0   # in-kernel all-reduces, none on the inner backend
