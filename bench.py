@@ -188,6 +188,8 @@ def main():
             # go through the host over gloo.  Exercises the multi-process flow, not its speed.
             dist.init_process_group("gloo")
             local_rank = 0
+            # (the resident cycle kernel wants every workgroup of its launch on the chip at once: N launches share one here)
+            os.environ.setdefault("SPK_RES_WGS", str(max(1, 240 // world)))
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -285,8 +287,28 @@ def main():
 
     # ---- warm-up: W untimed iterations
     phase[0] = "warm-up solve"
+    fallback = None
     if args.warmup > 0:
-        ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
+        # N > 1 with AUTO: the 1/8 slabs take the resident restart-cycle kernel, whose collectives run INSIDE one launch
+        # per cycle -- first contact with real xGMI windows happens here.  If it fails on ANY rank (a bounded wait gave
+        # up: SPK_ERR_COMM / SPK_ERR_HIP), every rank falls back to the launch-by-launch form 5 and the line says so.
+        failed, msg = 0, ""
+        try:
+            ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
+        except S.SpkError as ex:
+            if world == 1 or args.iter_form != 0:
+                raise
+            failed, msg = 1, str(ex)
+        if dist is not None and world > 1 and args.iter_form == 0:
+            import torch
+            t = torch.tensor([failed], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t.item()):
+                fallback = msg or "another rank's warm-up solve failed"
+                print(f"[bench] rank {rank}: warm-up with the resident cycle kernel failed ({fallback}); falling back to iteration form 5",
+                      file=sys.stderr, flush=True)
+                kw["iteration_form"] = 5
+                ctx.fgmres_device(b_dev, x_dev, max_it=args.warmup, **kw)
     # ---- timed: exactly K iterations
     phase[0] = "timed solve"
     elapsed, info = timed_solve(args.steps, **kw)
@@ -404,7 +426,7 @@ def main():
                                + f"FGMRES({args.restart}) CGS, pc={args.pc}",
                    "grid": M, "rows": n + (B.nrows if saddle else 0), "dim": args.dim, "pc": args.pc, "restart": args.restart,
                    "inner_fp32_sweeps": args.inner_sweeps, "iteration_form": args.iter_form, "iteration_form_run": form_run,
-                   "constraints": args.constraints if saddle else None,
+                   "constraints": args.constraints if saddle else None, "resident_fallback": fallback,
                    "reductions_per_iteration": 1 if (saddle and args.pc in ("schur-full", "schur-lower") and
                                                      args.single_reduce == 1) else 2,
                    "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",

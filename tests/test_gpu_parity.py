@@ -1160,19 +1160,30 @@ def test_bench_multi_process_flow_over_gloo(spk):
                           "--gpus", "2"] + common, capture_output=True, text=True, timeout=280, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     d1, d2 = last_json(one.stdout), last_json(two.stdout)
+    # AUTO: both take the resident restart-cycle kernel -- the two-process run with the ranks' sums and the halo rows crossing
+    # the IPC windows inside the one launch per cycle
+    assert d1["config"]["iteration_form_run"] == 6 and d2["config"]["iteration_form_run"] == 6
+    assert d2["config"]["resident_fallback"] is None and d2["residual_check"]["consistent"]
+    assert all(r["allreduce"]["fused"] > 0 and r["allreduce"]["inner"] == 0 for r in d2["ranks"])
     assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["steps"] == 45 and d2["scaling"] == "strong"
     assert d2["residual_after_steps"] == pytest.approx(d1["residual_after_steps"], rel=1e-6)
     assert d2["roofline"]["bytes_per_launch"] < d1["roofline"]["bytes_per_launch"]        # half the rows per rank
     # the two processes map each other's windows through HIP IPC: collectives by the solver's own kernels
     assert d2["config"]["collectives"] == "peer-store"
-    env4 = dict(env, SPK_BENCH_PEER="0")
-    off = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(root, "bench.py"),
-                          "--gpus", "2"] + common, capture_output=True, text=True, timeout=280, cwd=root, env=env4)
-    assert off.returncode == 0, off.stderr[-2000:]
-    d3 = last_json(off.stdout)
+    # the launch-by-launch form 5 with the collectives by the solver's kernels, and the same with the backend off: same sums,
+    # same order, same bits
+    runs = []
+    for port, e in ((29635, env), (29633, dict(env, SPK_BENCH_PEER="0"))):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--iter-form", "5"] + common, capture_output=True, text=True, timeout=280, cwd=root, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(last_json(r.stdout))
+    d5, d3 = runs
+    assert d5["config"]["collectives"] == "peer-store" and d5["config"]["iteration_form_run"] == 5
     assert d3["config"]["collectives"] == "host-callback"
-    assert d3["residual_after_steps"] == d2["residual_after_steps"]      # same sums, same order, same bits
+    assert d3["residual_after_steps"] == d5["residual_after_steps"]
+    assert d5["residual_after_steps"] == pytest.approx(d2["residual_after_steps"], rel=1e-6)
 
 
 def test_bench_inner_backend_rehearsal_four_processes_at_1024(spk):
