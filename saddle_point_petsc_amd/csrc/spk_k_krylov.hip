@@ -537,7 +537,7 @@ __global__ void krylov_refine_decide_kernel(KrylovArrays ka, int loc, int mode, 
                                             const double *nrm2, double *dots2)
 {
     KrylovState *st = ka.st;
-    if ((int)threadIdx.x <= loc) dots2[threadIdx.x] = 0.0;
+    for (int j = threadIdx.x; j <= loc; j += blockDim.x) dots2[j] = 0.0;   // (any restart length: the long-restart path too)
     if (threadIdx.x != 0) return;
     int skip = st->done ? 1 : 0;
     if (!skip && mode == SPK_REFINE_IFNEEDED) {
@@ -556,7 +556,7 @@ __global__ void krylov_refine_merge_kernel(KrylovArrays ka, int loc, double *dot
                                            double *nrm, const double *nrm_b, int nn)
 {
     if (ka.st->skip_refine) return;
-    if ((int)threadIdx.x <= loc) dots[threadIdx.x] += dots2[threadIdx.x];
+    for (int j = threadIdx.x; j <= loc; j += blockDim.x) dots[j] += dots2[j];
     if ((int)threadIdx.x < nn) nrm[threadIdx.x] = nrm_b[threadIdx.x];
 }
 void krylov_refine_merge(const KrylovArrays &ka, int loc, double *dots, const double *dots2, double *nrm,

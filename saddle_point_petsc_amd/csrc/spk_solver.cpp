@@ -1231,9 +1231,7 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // -ksp_gmres_restart beyond 62: the step-by-step path, Gram-Schmidt in chunks of <= 40 vectors (the fused kernels
     // keep one lane / one LDS slot per basis vector)
     const bool big = mk > k::kMaxNv - 2;
-    if (big && o.orthog == SPK_ORTHOG_CGS && o.cgs_refine != SPK_REFINE_NEVER)
-        fail(SPK_ERR_UNSUPPORTED, "fgmres: -ksp_gmres_cgs_refinement_type needs restart <= %d (restart %d)", k::kMaxNv - 2, mk);
-    if (big && c->bigdots.n < (size_t)mk + 4) c->bigdots.alloc((size_t)mk + 4);
+    if (big && c->bigdots.n < 2 * ((size_t)mk + 4)) c->bigdots.alloc(2 * ((size_t)mk + 4));   // first and refinement pass
     const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR && !big;
     const int m = c->m;
     const int32_t nl = c->n_local;
@@ -1639,6 +1637,25 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::maxpy(Vj(v0), ld, cnt, nullptr, db + v0, -1.0, w, N, n_dot, c->fin(lastc ? nb : nullptr), done, s);
                 }
                 c->comm->allreduce_sum(nb, nn, s);
+                if (o.cgs_refine != SPK_REFINE_NEVER) {
+                    // -ksp_gmres_cgs_refinement_type on a long restart: the second pass in the same chunks, on the device's
+                    // own decision (PETSc's ||w'|| < ||h|| test for ifneeded)
+                    const int32_t *skip = &c->kst.p->skip_refine;
+                    double *db2 = c->bigdots.p + (size_t)mk + 4;
+                    k::krylov_refine_decide(c->ka, loc, o.cgs_refine, db, nb, db2, s);
+                    for (int v0 = 0; v0 <= loc; v0 += 40) {
+                        const int cnt = std::min(40, loc + 1 - v0);
+                        k::mdot(Vj(v0), ld, cnt, w, N, n_dot, c->fin(db2 + v0), skip, s);
+                    }
+                    c->comm->allreduce_sum(db2, loc + 2, s);
+                    for (int v0 = 0; v0 <= loc; v0 += 40) {
+                        const int cnt = std::min(40, loc + 1 - v0);
+                        const bool lastc = v0 + 40 > loc;
+                        k::maxpy(Vj(v0), ld, cnt, nullptr, db2 + v0, -1.0, w, N, n_dot, c->fin(lastc ? nrm2b : nullptr), skip, s);
+                    }
+                    c->comm->allreduce_sum(nrm2b, nn, s);
+                    k::krylov_refine_merge(c->ka, loc, db, db2, nb, nrm2b, nn, s);
+                }
             } else {
                 // classical Gram-Schmidt: h = V^T w (one pass), w -= V h (+ ||w||^2 [+ B D w'] in the same pass)
                 // across ranks the all-reduces ride in the finish of the two kernels (peer-store backend)

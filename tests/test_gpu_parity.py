@@ -321,9 +321,18 @@ def test_long_restart_cycles(spk, oracle, restart, orthog):
         c.set_block(spk.BLOCK_A10, B)
         c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
         x, info = c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=4000, orthog=orthog)
-        if orthog == 0:
-            with pytest.raises(spk.SpkError):      # the refinement passes exist for restart <= 62 only: refused, not ignored
-                c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=10, cgs_refine=2)
+        refined = {}
+        if orthog == 0 and restart <= 200:
+            # -ksp_gmres_cgs_refinement_type on a long restart (round 3: the second pass runs in the same chunks)
+            for mode in (1, 2):
+                refined[mode] = c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=4000, cgs_refine=mode)
+    for mode, (xr, ir) in refined.items():
+        xro, iro = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, restart=restart, rtol=1e-10, max_it=4000,
+                                 refine=mode)
+        assert ir["reason"] == iro["reason"] == 2 and abs(ir["its"] - iro["its"]) <= 2, mode
+        kk = min(len(ir["history"]), len(iro["history"]), 150) - 1
+        assert np.allclose(ir["history"][:kk], iro["history"][:kk], rtol=1e-5), mode
+        assert relerr(xr, xro) < 1e-7
     xo, io = oracle.fgmres(A, rhs, B=B, pc_type=oracle.PC_SCHUR, schur_fact=3, restart=restart, rtol=1e-10, max_it=4000,
                            orthog=orthog)
     assert info["reason"] == io["reason"] == 2 and abs(info["its"] - io["its"]) <= 2

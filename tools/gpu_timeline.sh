@@ -1,0 +1,5 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d /tmp/prof_t -o run -- python3 $R/bench.py --grid 1024 --grid-y 128 --no-cpu-baseline --steps 120 --warmup 30 > /dev/null 2> $R/gpurun_out/timeline.err
+python3 $R/tools/rocpd_timeline.py /tmp/prof_t/run_results.db 6 16 3
