@@ -25,8 +25,11 @@
 namespace spk {
 namespace k {
 
+#ifndef SPK_DICT_MINW
+#define SPK_DICT_MINW 1
+#endif
 template <int BS, bool ACC, bool RIDE, bool BT>
-__global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
+__global__ __launch_bounds__(kThreads, SPK_DICT_MINW) void spmv_dict_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
                                                              const int32_t *__restrict__ bt_rowptr,
                                                              const int32_t *__restrict__ bt_colidx,
                                                              const double *__restrict__ bt_val, const double *__restrict__ lam,
@@ -91,7 +94,10 @@ __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const d
         }
         const int len = tlen[tc];
         const int2 *te = tent + (size_t)tc * d.kmax;
-        constexpr int G = BS == 2 ? 9 : 3;   // blocks whose loads are in flight together (a 2-D interior row: all nine)
+#ifndef SPK_DICT_G
+#define SPK_DICT_G 9
+#endif
+        constexpr int G = BS == 2 ? SPK_DICT_G : 3;   // blocks whose loads are in flight together (a 2-D interior row: all nine)
         for (int k0 = 0; k0 < len; k0 += G) {
             int2 e[G];
             DictRaw<BS> raw[G];
