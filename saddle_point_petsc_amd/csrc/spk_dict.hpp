@@ -8,6 +8,7 @@ namespace k {
 
 constexpr int kDictChunk = kThreads;   // block rows per chunk: one per thread
 typedef int int2v __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
 
 // ---------------------------------------------------------------------------
 // the product
@@ -15,79 +16,86 @@ typedef int int2v __attribute__((ext_vector_type(2)));
 struct DictArgs {
     const uint16_t *tid;
     const int32_t *tab;
-    const double *cls;             // nclass x bs*bs x {base, scale}
+    const double *cls;             // nclass x bs*bs x {base, 2^g}
+    const int32_t *fld;            // nclass x bs*bs bit fields: shift | width << 8 | word << 16
     const unsigned char *codes;
     int32_t nbrows, ntype, nclass, kmax;
-    int64_t nbrows_pad;            // rows of a code plane (nbrows rounded up to 16); a wide position has two planes
     int32_t nchunks, chunks_per_xcd, chunks_per_wg;
-    int32_t tab_ints, cls_off;     // ints of the type tables; byte offset of the class table in LDS
-    uint32_t wide_mask;            // bit k: position k of a block row holds 32-bit codes
-    int64_t plane_off[kDictMaxK];  // byte offset of the code plane of position k
+    int32_t tab_ints, cls_off, fld_off;   // ints of the type tables; byte offsets of the class and field tables in LDS
+    // code planes.  bs = 2: one 64-bit word per block, the words of positions 2p and 2p+1 of a block row side by side in
+    // plane p (16 bytes per block row: one full-width load; an odd last position: a plane of 8-byte words).
+    // bs = 3: two words per block, plane k = position k (16 bytes per block row)
+    int64_t plane_off[kDictMaxK];
 };
-
-// bytes of one block's 16-bit halves in a plane: bs = 2 -- four in 8 bytes; bs = 3 -- three rows of three, each row in 8
-__host__ __device__ constexpr int dict_block_bytes(int bs) { return bs == 2 ? 8 : 24; }
 
 // tables -> LDS (every workgroup; a few KB out of L2)
 __device__ __forceinline__ void dict_load_lds(const DictArgs &d, int nclsvals, char *smem)
 {
     int32_t *ti = reinterpret_cast<int32_t *>(smem);
-    for (int i = threadIdx.x; i < d.tab_ints; i += kThreads) ti[i] = d.tab[i];
+    for (int i = threadIdx.x; i < d.tab_ints; i += blockDim.x) ti[i] = d.tab[i];
     double2 *cv = reinterpret_cast<double2 *>(smem + d.cls_off);
     const double2 *src = reinterpret_cast<const double2 *>(d.cls);
-    for (int i = threadIdx.x; i < nclsvals; i += kThreads) cv[i] = src[i];
+    for (int i = threadIdx.x; i < nclsvals; i += blockDim.x) cv[i] = src[i];
+    int32_t *fl = reinterpret_cast<int32_t *>(smem + d.fld_off);
+    for (int i = threadIdx.x; i < nclsvals; i += blockDim.x) fl[i] = d.fld[i];
     __syncthreads();
 }
 
-// The codes of block position k of block row br, as stored: every position has a plane of 16-bit LOW halves (bs = 2:
-// four in 8 bytes; bs = 3: three rows of three, each row in 8 bytes); a WIDE position has a second plane of the same
-// shape with the high halves, adjusted so that code = sext(low) + (high << 16) needs no case distinction.  Narrow
-// positions leave `hi` at zero.  The loads are issued here, unconditionally but for the one uniform test, and unpacked
-// later (dict_unpack): nothing below waits for memory, so a row's loads are all in flight together.
-template <int BS>
-struct DictRaw {
-    int2v lo[BS == 2 ? 1 : 3], hi[BS == 2 ? 1 : 3];
-};
-template <int BS>
-__device__ __forceinline__ void dict_issue(const DictArgs &d, int k, int64_t br, DictRaw<BS> &w)
+// The stored form of a block: its bs*bs integer deviations k (value = base + k 2^g), each as a two's-complement BIT FIELD
+// of the width its class entry needs (1 .. 31 bits; the widths of a class fit 64 bits for 2x2 blocks, twice 64 for 3x3
+// ones), packed into one / two 64-bit words.  Loads are issued first and unpacked later: a row's loads are all in flight
+// together, all of them 16 bytes per lane but an odd last position of a dof-2 row.
+__device__ __forceinline__ void dict_issue_pair2(const DictArgs &d, int p, int64_t br, u64 &w0, u64 &w1)
 {
-    constexpr int R = BS == 2 ? 1 : 3;
-    const bool wide = (d.wide_mask >> k) & 1u;
-    const int2v *p = reinterpret_cast<const int2v *>(d.codes + d.plane_off[k]) + R * br;
-#pragma unroll
-    for (int r = 0; r < R; ++r) w.lo[r] = __builtin_nontemporal_load(p + r);
-#pragma unroll
-    for (int r = 0; r < R; ++r) w.hi[r] = int2v{0, 0};
-    if (wide) {
-        const int2v *q = p + (int64_t)R * d.nbrows_pad;
-#pragma unroll
-        for (int r = 0; r < R; ++r) w.hi[r] = __builtin_nontemporal_load(q + r);
+    const unsigned char *base = d.codes + d.plane_off[p];
+    if (2 * p + 1 < d.kmax) {
+        const int4v r = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(base) + br);
+        w0 = (u64)(uint32_t)r.x | ((u64)(uint32_t)r.y << 32);
+        w1 = (u64)(uint32_t)r.z | ((u64)(uint32_t)r.w << 32);
+    } else {
+        const int2v r = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(base) + br);
+        w0 = (u64)(uint32_t)r.x | ((u64)(uint32_t)r.y << 32);
+        w1 = 0ull;
     }
 }
-template <int BS>
-__device__ __forceinline__ void dict_unpack(const DictRaw<BS> &w, int (&c)[BS * BS])
+__device__ __forceinline__ void dict_issue3(const DictArgs &d, int k, int64_t br, u64 &w0, u64 &w1)
 {
-    constexpr int R = BS == 2 ? 1 : 3;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int l0 = (int)(short)(w.lo[r].x & 0xffff), l1 = w.lo[r].x >> 16, l2 = (int)(short)(w.lo[r].y & 0xffff), l3 = w.lo[r].y >> 16;
-        const int h0 = (int)(short)(w.hi[r].x & 0xffff), h1 = w.hi[r].x >> 16, h2 = (int)(short)(w.hi[r].y & 0xffff), h3 = w.hi[r].y >> 16;
-        if (BS == 2) {
-            c[0] = l0 + h0 * 65536;
-            c[1] = l1 + h1 * 65536;
-            c[2] = l2 + h2 * 65536;
-            c[3] = l3 + h3 * 65536;
-        } else {
-            c[3 * r] = l0 + h0 * 65536;
-            c[3 * r + 1] = l1 + h1 * 65536;
-            c[3 * r + 2] = l2 + h2 * 65536;
-        }
-    }
+    const int4v r = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(d.codes + d.plane_off[k]) + br);
+    w0 = (u64)(uint32_t)r.x | ((u64)(uint32_t)r.y << 32);
+    w1 = (u64)(uint32_t)r.z | ((u64)(uint32_t)r.w << 32);
+}
+// field fd = shift | width << 8 | word << 16 of (w0, w1), sign-extended
+__device__ __forceinline__ int dict_field_exact(u64 w0, u64 w1, int fd)
+{
+    const u64 w = (fd >> 16) ? w1 : w0;
+    const int sh = fd & 255, wd = (fd >> 8) & 255;
+    return (int)((long long)(w << (64 - sh - wd)) >> (64 - wd));
+}
+__device__ __forceinline__ int dict_field(u64 w0, u64 w1, int fd)
+{
+#if defined(SPK_DICT_X_NOFIELD)      /* timing experiments only: wrong results */
+    return (int)w0 + fd;
+#elif defined(SPK_DICT_X_ONESHIFT)
+    return (int)(((fd >> 16) ? w1 : w0) >> (fd & 63));
+#else
+    const u64 w = (fd >> 16) ? w1 : w0;
+    const int sh = fd & 255, wd = (fd >> 8) & 255;
+    return (int)((long long)(w << (64 - sh - wd)) >> (64 - wd));
+#endif
 }
 // value = base + k * 2^g: both terms exact, the sum representable (it is the stored value): exact under any rounding
 __device__ __forceinline__ double dict_decode(int code, double2 bs)
 {
     return __builtin_fma((double)code, bs.y, bs.x);
+}
+// address of the word(s) of position k of block row br (set-up kernels, the resident kernel's LDS copy)
+template <int BS>
+__device__ __forceinline__ u64 *dict_word_ptr(const DictArgs &d, unsigned char *codes, int k, int64_t br)
+{
+    if (BS == 3) return reinterpret_cast<u64 *>(codes + d.plane_off[k]) + 2 * br;
+    const int p = k >> 1;
+    if (2 * p + 1 < d.kmax) return reinterpret_cast<u64 *>(codes + d.plane_off[p]) + 2 * br + (k & 1);
+    return reinterpret_cast<u64 *>(codes + d.plane_off[p]) + br;
 }
 
 inline DictArgs dict_args(const DictDev &A, int *grid)
@@ -96,12 +104,12 @@ inline DictArgs dict_args(const DictDev &A, int *grid)
     d.tid = A.tid.p;
     d.tab = A.tab.p;
     d.cls = A.cls.p;
+    d.fld = A.fld.p;
     d.codes = A.codes.p;
     d.nbrows = A.nbrows;
     d.ntype = A.ntype;
     d.nclass = A.nclass;
     d.kmax = A.kmax;
-    d.nbrows_pad = ((int64_t)A.nbrows + 15) & ~(int64_t)15;
     d.nchunks = (A.nbrows + kDictChunk - 1) / kDictChunk;
     // large systems: a few chunks per workgroup (the table copy is paid once per workgroup), about 2048 workgroups
     d.chunks_per_wg = std::max(1, d.nchunks / 2048);
@@ -109,7 +117,7 @@ inline DictArgs dict_args(const DictDev &A, int *grid)
     d.chunks_per_xcd = (cpx + d.chunks_per_wg - 1) / d.chunks_per_wg * d.chunks_per_wg;
     d.tab_ints = ((A.ntype + 1) & ~1) + 2 * A.ntype * A.kmax;
     d.cls_off = (4 * d.tab_ints + 15) & ~15;
-    d.wide_mask = A.wide_mask;
+    d.fld_off = d.cls_off + 16 * A.nclass * A.bs * A.bs;
     for (int k = 0; k < kDictMaxK; ++k) d.plane_off[k] = A.plane_off[k];
     *grid = 8 * (d.chunks_per_xcd / d.chunks_per_wg);
     return d;

@@ -139,8 +139,8 @@ struct Bcsr3Dev {
 // The two small tables sit in LDS.  A product streams x, y and ~2.1 B per stored non-zero instead of 9 (blocked) / 12
 // (CSR) and forms the same products in the same order: bit-identical sums.  Found in the caller's CSR at KSPSetOperators
 // (hashing on the device, then EVERY value decoded and compared bit by bit); a matrix that does not fit (too many classes
-// or types, a row beyond kDictMaxK blocks, deviations that are not small multiples of one power of two, tables beyond the
-// LDS budget) keeps the plain blocked layout.
+// or types, a row beyond kDictMaxK blocks, deviations that are not small multiples of one power of two or do not fit the
+// words, tables beyond the LDS budget) keeps the plain blocked layout.
 constexpr int kDictMaxK = 32;      // blocks per block row
 struct DictDev {
     int bs = 0;
@@ -149,10 +149,10 @@ struct DictDev {
     DevBuf<uint16_t> tid;          // type of every block row
     DevBuf<int32_t> tab;           // [ntype] lengths (padded to an even count), then ntype x kmax x {column offset, class}
     DevBuf<double> cls;            // nclass x bs*bs x {base, 2^g}
-    DevBuf<unsigned char> codes;   // per block position k: a plane of 16-bit low halves (nbrows x 8 | 24 bytes for bs = 2 | 3), and behind it,
-                                   // for a position with 32-bit codes, a plane of high halves: code = sext(low) + (high << 16)
+    DevBuf<int32_t> fld;           // nclass x bs*bs bit fields of the codes: shift | width << 8 | word << 16
+    DevBuf<unsigned char> codes;   // bs = 2: one 64-bit word per block, positions 2p / 2p+1 side by side in plane p (16 B per block
+                                   // row; an odd last position: 8 B); bs = 3: two words per block, plane k = position k
     int64_t plane_off[kDictMaxK] = {};
-    uint32_t wide_mask = 0;        // bit k: position k holds 32-bit codes
     int64_t code_bytes = 0;        // bytes of codes a product reads (the planes without their padding rows)
     int32_t lds_bytes = 0;         // tables as laid out in LDS
     bool ok = false;

@@ -25,11 +25,8 @@
 namespace spk {
 namespace k {
 
-#ifndef SPK_DICT_MINW
-#define SPK_DICT_MINW 1
-#endif
 template <int BS, bool ACC, bool RIDE, bool BT>
-__global__ __launch_bounds__(kThreads, SPK_DICT_MINW) void spmv_dict_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
+__global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
                                                              const int32_t *__restrict__ bt_rowptr,
                                                              const int32_t *__restrict__ bt_colidx,
                                                              const double *__restrict__ bt_val, const double *__restrict__ lam,
@@ -54,6 +51,7 @@ __global__ __launch_bounds__(kThreads, SPK_DICT_MINW) void spmv_dict_kernel(Dict
     const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
     const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
     const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);
+    const int32_t *fl = reinterpret_cast<const int32_t *>(smem + d.fld_off);
 
     for (int ch = c0; ch < c1; ++ch) {
         const int tc = tidn;
@@ -94,20 +92,25 @@ __global__ __launch_bounds__(kThreads, SPK_DICT_MINW) void spmv_dict_kernel(Dict
         }
         const int len = tlen[tc];
         const int2 *te = tent + (size_t)tc * d.kmax;
-#ifndef SPK_DICT_G
-#define SPK_DICT_G 9
-#endif
-        constexpr int G = BS == 2 ? SPK_DICT_G : 3;   // blocks whose loads are in flight together (a 2-D interior row: all nine)
+        // blocks whose loads are in flight together: a 2-D interior row whole (five 16-byte code loads + nine gathers of x)
+        constexpr int G = BS == 2 ? 10 : 3;
         for (int k0 = 0; k0 < len; k0 += G) {
             int2 e[G];
-            DictRaw<BS> raw[G];
+            u64 w0[G], w1[BS == 2 ? 1 : G];
             double xv[G][BS];
+            if (BS == 2) {
+#pragma unroll
+                for (int h = 0; h < G / 2; ++h) {
+                    w0[2 * h] = w0[2 * h + 1] = 0ull;
+                    if (k0 + 2 * h < len) dict_issue_pair2(d, (k0 >> 1) + h, brc, w0[2 * h], w0[2 * h + 1]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const bool in = k0 + g < len;
                 e[g] = in ? te[k0 + g] : make_int2(0, 0);
                 if (in) {
-                    dict_issue<BS>(d, k0 + g, brc, raw[g]);
+                    if (BS == 3) dict_issue3(d, k0 + g, brc, w0[g], w1[BS == 2 ? 0 : g]);
                     const int64_t c = (int64_t)brc + e[g].x;
                     if (BS == 2) {
                         const double2 t = reinterpret_cast<const double2 *>(x)[c];
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(kThreads, SPK_DICT_MINW) void spmv_dict_kernel(Dict
             for (int g = 0; g < G; ++g) {
                 if (k0 + g < len) {
                     const double2 *cb = cv + (size_t)e[g].y * (BS * BS);
-                    int code[BS * BS];
-                    dict_unpack<BS>(raw[g], code);
+                    const int32_t *fb = fl + (size_t)e[g].y * (BS * BS);
 #pragma unroll
                     for (int r = 0; r < BS; ++r)
 #pragma unroll
-                        for (int j = 0; j < BS; ++j) s[r] += dict_decode(code[r * BS + j], cb[r * BS + j]) * xv[g][j];
+                        for (int j = 0; j < BS; ++j)
+                            s[r] += dict_decode(dict_field(w0[g], BS == 2 ? 0ull : w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * xv[g][j];
                 }
             }
         }
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArg
     const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
     const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
     const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);
+    const int32_t *fl = reinterpret_cast<const int32_t *>(smem + d.fld_off);
     for (int ch = c0; ch < c1; ++ch) {
         const int br = ch * kDictChunk + (int)threadIdx.x;
         if (br >= d.nbrows) continue;
@@ -226,17 +230,24 @@ __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArg
         for (int r = 0; r < BS; ++r) s[r] = 0.0f;
         const int len = tlen[tc];
         const int2 *te = tent + (size_t)tc * d.kmax;
-        constexpr int G = BS == 2 ? 9 : 3;
+        constexpr int G = BS == 2 ? 10 : 3;
         for (int k0 = 0; k0 < len; k0 += G) {
             int2 e[G];
-            DictRaw<BS> raw[G];
+            u64 w0[G], w1[BS == 2 ? 1 : G];
             float yv[G][BS];
+            if (BS == 2) {
+#pragma unroll
+                for (int h = 0; h < G / 2; ++h) {
+                    w0[2 * h] = w0[2 * h + 1] = 0ull;
+                    if (k0 + 2 * h < len) dict_issue_pair2(d, (k0 >> 1) + h, br, w0[2 * h], w0[2 * h + 1]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const bool in = k0 + g < len;
                 e[g] = in ? te[k0 + g] : make_int2(0, 0);
                 if (in) {
-                    dict_issue<BS>(d, k0 + g, br, raw[g]);
+                    if (BS == 3) dict_issue3(d, k0 + g, br, w0[g], w1[BS == 2 ? 0 : g]);
                     const int64_t c = (int64_t)br + e[g].x;
 #pragma unroll
                     for (int j = 0; j < BS; ++j) yv[g][j] = yin[BS * c + j];
@@ -246,12 +257,12 @@ __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArg
             for (int g = 0; g < G; ++g) {
                 if (k0 + g < len) {
                     const double2 *cb = cv + (size_t)e[g].y * (BS * BS);
-                    int code[BS * BS];
-                    dict_unpack<BS>(raw[g], code);
+                    const int32_t *fb = fl + (size_t)e[g].y * (BS * BS);
 #pragma unroll
                     for (int r = 0; r < BS; ++r)
 #pragma unroll
-                        for (int j = 0; j < BS; ++j) s[r] = (s[r] + ((float)dict_decode(code[r * BS + j], cb[r * BS + j]) * yv[g][j]));
+                        for (int j = 0; j < BS; ++j)
+                            s[r] = (s[r] + ((float)dict_decode(dict_field(w0[g], BS == 2 ? 0ull : w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * yv[g][j]));
                 }
             }
         }
@@ -492,8 +503,8 @@ void dict_fill_rows(const int32_t *browptr, const int32_t *bcol, const int32_t *
                        nbrows, nid, kmax, slot2id, slot, tab, tid, bad);
 }
 
-// codes: k = (value - base) / 2^g into the plane of the block's position; then every value decoded as the product
-// kernels decode it and compared bit by bit (*bad)
+// codes: k = (value - base) / 2^g as a bit field of its class entry's width in the block's word(s); then every value decoded
+// as the product kernels decode it and compared bit by bit (*bad)
 template <int BS>
 __global__ __launch_bounds__(kThreads) void dict_encode_kernel(DictArgs d, const int32_t *__restrict__ browptr,
                                                                const int32_t *__restrict__ blkid, const double *__restrict__ v0,
@@ -505,24 +516,24 @@ __global__ __launch_bounds__(kThreads) void dict_encode_kernel(DictArgs d, const
     const int q0 = browptr[br], len = browptr[br + 1] - q0;
     for (int k = 0; k < len; ++k) {
         const int id = blkid[q0 + k];
-        const bool wide = (d.wide_mask >> k) & 1u;
-        int16_t *plo = reinterpret_cast<int16_t *>(codes + d.plane_off[k] + (size_t)dict_block_bytes(BS) * br);
-        int16_t *phi = plo + (size_t)(dict_block_bytes(BS) / 2) * d.nbrows_pad;
+        u64 w[2] = {0ull, 0ull};
 #pragma unroll
         for (int r = 0; r < BS; ++r)
 #pragma unroll
             for (int j = 0; j < BS; ++j) {
                 const int e = r * BS + j;
                 const double base = d.cls[2 * (id * BS * BS + e)], sc = d.cls[2 * (id * BS * BS + e) + 1];
+                const int fd = d.fld[id * BS * BS + e];
+                const int sh = fd & 255, wd = (fd >> 8) & 255, wi = fd >> 16;
                 const double kq = (blk_val<BS>(v0, v1, ldp, q0 + k, r, j) - base) / sc;
                 const long long kk = (long long)rint(kq);
-                if ((double)kk != kq || kk < (wide ? -1000000000ll : -32767ll) || kk > (wide ? 1000000000ll : 32767ll)) *bad = 1;
-                const int pos = BS == 2 ? e : 4 * r + j;   // bs = 3: three rows of three codes, padded to four
-                const int32_t k32 = (int32_t)kk;
-                const int16_t lo = (int16_t)(k32 & 0xffff);
-                plo[pos] = lo;
-                if (wide) phi[pos] = (int16_t)((k32 - (int32_t)lo) >> 16);   // code = sext(lo) + (hi << 16)
+                const long long lim = 1ll << (wd - 1);
+                if ((double)kk != kq || kk < -lim || kk > lim - 1) *bad = 1;
+                w[wi] |= ((u64)kk & ((wd >= 64) ? ~0ull : ((1ull << wd) - 1ull))) << sh;
             }
+        u64 *p = dict_word_ptr<BS>(d, codes, k, br);
+        p[0] = w[0];
+        if (BS == 3) p[1] = w[1];
     }
 }
 template <int BS>
@@ -537,17 +548,23 @@ __global__ __launch_bounds__(kThreads) void dict_verify_kernel(DictArgs d, const
     const int32_t *ent = d.tab + ((d.ntype + 1) & ~1) + 2 * (size_t)t * d.kmax;
     bool ok = t < d.ntype && d.tab[t] == len;
     for (int k = 0; ok && k < len; ++k) {
-        int code[BS * BS];
-        DictRaw<BS> raw;
-        dict_issue<BS>(d, k, br, raw);
-        dict_unpack<BS>(raw, code);
+        u64 w0 = 0ull, w1 = 0ull;
+        if (BS == 2) {
+            u64 a0, a1;
+            dict_issue_pair2(d, k >> 1, br, a0, a1);
+            w0 = (k & 1) ? a1 : a0;
+        } else {
+            dict_issue3(d, k, br, w0, w1);
+        }
         ok = ok && bcol[q0 + k] == (int)br + ent[2 * k];
-        const double2 *cb = reinterpret_cast<const double2 *>(d.cls) + (size_t)ent[2 * k + 1] * (BS * BS);
+        const int cls_id = ent[2 * k + 1];
+        const double2 *cb = reinterpret_cast<const double2 *>(d.cls) + (size_t)cls_id * (BS * BS);
+        const int32_t *fb = d.fld + (size_t)cls_id * (BS * BS);
 #pragma unroll
         for (int r = 0; r < BS; ++r)
 #pragma unroll
             for (int j = 0; j < BS; ++j)
-                ok = ok && __double_as_longlong(dict_decode(code[r * BS + j], cb[r * BS + j])) ==
+                ok = ok && __double_as_longlong(dict_decode(dict_field_exact(w0, w1, fb[r * BS + j]), cb[r * BS + j])) ==
                                __double_as_longlong(blk_val<BS>(v0, v1, ldp, q0 + k, r, j));
     }
     if (!ok) *bad = 1;

@@ -120,7 +120,6 @@ struct ResArgs {
     DictArgs d;
     int G, rpw;            // workgroups; block rows per workgroup (<= T)
     int mk, m, np, packed, fact, lam_in_dot;   // np: planes of B D actually present (<= NP of the instantiation)
-    int nwide;             // block positions with 32-bit codes
     int64_t nl, ld;
     const double *V0, *V1; // v_0 (normalised) and w~ = K z_0 (first product of the cycle, made by the launches before)
     double *Z;             // Z_j = Z + j ld: Z_1 .. written here (rows armed with the sentinel)
@@ -160,9 +159,8 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
     constexpr int MAXIT = (kResMaxVals * 32 + T - 1) / T;        // all-to-all items (value, chunk of 8 workgroups) per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS: matrix tables | code planes of this workgroup's rows | product staging | scalar work space
-    int2v *clo = reinterpret_cast<int2v *>(smem + a.tab_bytes);  // kmax x T low halves, then nwide x T high halves
-    int2v *chi = clo + (size_t)a.d.kmax * T;
-    double *prod = reinterpret_cast<double *>(chi + (size_t)a.nwide * T);   // kResPass x LDP; also the all-to-all partials
+    u64 *cwd = reinterpret_cast<u64 *>(smem + a.tab_bytes);        // kmax x T: the code word of every block of this workgroup's rows
+    double *prod = reinterpret_cast<double *>(cwd + (size_t)a.d.kmax * T);   // kResPass x LDP; also the all-to-all partials
     double *ws = prod + kResPass * LDP;
     double *dots = ws;                      // 64
     double *dotsg = dots + 64;              // 64: the same summed over the ranks
@@ -209,17 +207,9 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
         pe[q].x = pe[q].y = 0.0;
         if (active && q < a.np) pe[q] = ld2(a.bd + (size_t)q * a.ldb, br);
     }
-    {   // the codes of this thread's block row: read once per cycle, decoded out of LDS in every product
-        int wi = 0;
-        for (int k = 0; k < a.d.kmax; ++k) {
-            const int2v *p = reinterpret_cast<const int2v *>(a.d.codes + a.d.plane_off[k]);
-            clo[k * T + t] = active ? p[br] : int2v{0, 0};
-            if ((a.d.wide_mask >> k) & 1u) {
-                chi[wi * T + t] = active ? p[a.d.nbrows_pad + br] : int2v{0, 0};
-                ++wi;
-            }
-        }
-    }
+    // the codes of this thread's block row: read once per cycle, decoded out of LDS in every product
+    for (int k = 0; k < a.d.kmax; ++k)
+        cwd[k * T + t] = active ? *dict_word_ptr<2>(a.d, const_cast<unsigned char *>(a.d.codes), k, br) : 0ull;
     dict_load_lds(a.d, a.d.nclass * 4, smem);   // (ends with a barrier)
     if (L->done || L->skip_iter) return;         // uniform: set by krylov_cycle_begin before this launch
     if (t < m) {
@@ -236,6 +226,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
     const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
     const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((a.d.ntype + 1) & ~1));
     const double2 *cv = reinterpret_cast<const double2 *>(smem + a.d.cls_off);
+    const int32_t *fl = reinterpret_cast<const int32_t *>(smem + a.d.fld_off);
     const int len = active ? tlen[tid] : 0;
     const int2 *te = tent + (size_t)tid * a.d.kmax;
     const int nch = (a.G + 7) / 8;
@@ -582,16 +573,12 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                     if (k0 + g < len) {
                         const int k = k0 + g;
                         const double2 *cb = cv + (size_t)e[g].y * 4;
-                        DictRaw<2> raw;
-                        raw.lo[0] = clo[k * T + t];
-                        raw.hi[0] = int2v{0, 0};
-                        if ((a.d.wide_mask >> k) & 1u) raw.hi[0] = chi[__builtin_popcount(a.d.wide_mask & ((1u << k) - 1u)) * T + t];
-                        int code[4];
-                        dict_unpack<2>(raw, code);
-                        s0 += dict_decode(code[0], cb[0]) * xv[g][0];
-                        s0 += dict_decode(code[1], cb[1]) * xv[g][1];
-                        s1 += dict_decode(code[2], cb[2]) * xv[g][0];
-                        s1 += dict_decode(code[3], cb[3]) * xv[g][1];
+                        const int32_t *fb = fl + (size_t)e[g].y * 4;
+                        const u64 wd = cwd[k * T + t];
+                        s0 += dict_decode(dict_field(wd, 0ull, fb[0]), cb[0]) * xv[g][0];
+                        s0 += dict_decode(dict_field(wd, 0ull, fb[1]), cb[1]) * xv[g][1];
+                        s1 += dict_decode(dict_field(wd, 0ull, fb[2]), cb[2]) * xv[g][0];
+                        s1 += dict_decode(dict_field(wd, 0ull, fb[3]), cb[3]) * xv[g][1];
                     }
                 }
             }
@@ -662,7 +649,7 @@ static int res_grid_cap(int num_cus)
 size_t resident_lds_bytes(const DictDev &A, int T)
 {
     const size_t tab = ((size_t)A.lds_bytes + 15) & ~(size_t)15;
-    const size_t codes = (size_t)(A.kmax + __builtin_popcount(A.wide_mask)) * T * 8;
+    const size_t codes = (size_t)A.kmax * T * 8;
     const size_t dbl = (size_t)kResPass * (T + 8) + 128 + 32 + 68 + 34 * 5 + 32 * 8 * 2 + 8 * 6 + 64;
     return tab + codes + dbl * sizeof(double) + sizeof(KrylovState) + 64;
 }
@@ -690,7 +677,6 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
     a.G = G;
     a.rpw = rpw;
     a.mk = r.mk; a.m = r.m; a.np = np; a.packed = r.packed; a.fact = r.fact; a.lam_in_dot = r.lam_in_dot;
-    a.nwide = __builtin_popcount(A.wide_mask);
     a.nl = r.nl; a.ld = r.ld;
     a.V0 = r.V0; a.V1 = r.V1; a.Z = r.Z; a.dinv = r.dinv; a.bd = r.bd; a.ldb = r.ldb; a.shat = r.shat; a.gram = r.gram;
     a.P = r.P; a.ka = r.ka; a.sc_out = r.sc_out; a.err = r.err; a.ticks = r.ticks;

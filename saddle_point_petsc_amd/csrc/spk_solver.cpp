@@ -158,12 +158,12 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
 {
     DictDev &D = c->Adict;
     D.ok = false;
-    D.tid.release(); D.tab.release(); D.cls.release(); D.codes.release();
+    D.tid.release(); D.tab.release(); D.cls.release(); D.fld.release(); D.codes.release();
     const char *fmt = getenv("SPK_SPMV_FORMAT");
     if (fmt && (!strcmp(fmt, "csr") || !strcmp(fmt, "bcsr"))) return;
     static const bool verbose = getenv("SPK_DICT_VERBOSE") != nullptr;
     auto refuse = [&](const char *why, long a = 0, long b = 0) {
-        D.tid.release(); D.tab.release(); D.cls.release(); D.codes.release();
+        D.tid.release(); D.tab.release(); D.cls.release(); D.fld.release(); D.codes.release();
         if (verbose) fprintf(stderr, "[spk] row types + codes refused: %s (%ld, %ld)\n", why, a, b);
     };
     hipStream_t s = c->stream;
@@ -233,21 +233,35 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
     SPK_HIP(hipStreamSynchronize(s));
     if (hbad) return refuse("a deviation from its class base is not exactly representable");
-    std::vector<char> cls_wide((size_t)ncls, 0);
-    for (int i = 0; i < ncls * bb; ++i) {
-        double scale = 1.0;
-        if (hg[(size_t)i] < 0x7f000000) {   // some member deviates: granule = the finest bit in use
-            if (hg[(size_t)i] < -1000 || hg[(size_t)i] > 1000) return refuse("deviation granule out of range", i, hg[(size_t)i]);
-            scale = std::ldexp(1.0, hg[(size_t)i]);
-            double mag;
-            std::memcpy(&mag, &hm[(size_t)i], sizeof mag);
-            const double kabs = mag / scale;
-            if (!(kabs <= 1.0e9)) return refuse("a class scatters beyond 32-bit codes", i, (long)hg[(size_t)i]);
-            if (kabs > 32767.0) cls_wide[(size_t)(i / bb)] = 1;
+    // bit fields: entry (class, e) gets the width its largest deviation needs (two's complement), the fields of a block are
+    // packed into one 64-bit word (2x2 blocks) or two (3x3: a field never straddles the words)
+    std::vector<int32_t> hfld((size_t)ncls * bb, 0);
+    for (int cl = 0; cl < ncls; ++cl) {
+        int used[2] = {0, 0}, word = 0;
+        for (int e = 0; e < bb; ++e) {
+            const int i = cl * bb + e;
+            double scale = 1.0;
+            int width = 1;
+            if (hg[(size_t)i] < 0x7f000000) {   // some member deviates: granule = the finest bit in use
+                if (hg[(size_t)i] < -1000 || hg[(size_t)i] > 1000) return refuse("deviation granule out of range", i, hg[(size_t)i]);
+                scale = std::ldexp(1.0, hg[(size_t)i]);
+                double mag;
+                std::memcpy(&mag, &hm[(size_t)i], sizeof mag);
+                const double kabs = mag / scale;
+                if (!(kabs <= 1.0e9)) return refuse("a class entry scatters beyond 31-bit codes", i, (long)hg[(size_t)i]);
+                width = 2;
+                while ((double)((1ll << (width - 1)) - 1) < kabs) ++width;
+            }
+            if (used[word] + width > 64) ++word;
+            if (word > (bs == 2 ? 0 : 1)) return refuse("the codes of a block class do not fit its word(s)", cl, used[0] + used[1] + width);
+            hfld[(size_t)i] = used[word] | (width << 8) | (word << 16);
+            used[word] += width;
+            hcls[(size_t)2 * i + 1] = scale;
         }
-        hcls[(size_t)2 * i + 1] = scale;
     }
     SPK_HIP(hipMemcpyAsync(D.cls.p, hcls.data(), sizeof(double) * hcls.size(), hipMemcpyHostToDevice, s));
+    D.fld.alloc_raw((size_t)ncls * bb, 8);
+    SPK_HIP(hipMemcpyAsync(D.fld.p, hfld.data(), sizeof(int32_t) * hfld.size(), hipMemcpyHostToDevice, s));
     // ---- row types
     DevBuf<int32_t> rslot;
     rslot.alloc_raw((size_t)nbr, 8);
@@ -258,7 +272,7 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     int kmax = 1;
     for (int32_t r : reps) kmax = std::max(kmax, brp[(size_t)r + 1] - brp[(size_t)r]);
     const int tab_ints = ((ntype + 1) & ~1) + 2 * ntype * kmax;
-    const int lds_bytes = ((4 * tab_ints + 15) & ~15) + 16 * ncls * bb;
+    const int lds_bytes = ((((4 * tab_ints + 15) & ~15) + 16 * ncls * bb + 4 * ncls * bb) + 15) & ~15;
     if (lds_bytes > k::kDictLdsMax) return refuse("tables beyond the LDS budget", lds_bytes, ntype);
     D.tab.alloc((size_t)tab_ints, 8);
     D.tid.alloc_raw((size_t)nbr, 64);
@@ -268,17 +282,17 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
     SPK_HIP(hipStreamSynchronize(s));
     if (hbad) return refuse("row type verification failed (hash collision)", ntype, ncls);
-    // ---- code planes: position k of every block row; 32-bit codes where any type puts a wide class there
-    D.wide_mask = 0;
-    std::vector<int64_t> rows_at((size_t)kmax, 0);   // (for the byte model: rows that have a block at position k -- all, up to the few short types)
-    for (int t = 0; t < ntype; ++t)
-        for (int kk = 0; kk < htab[(size_t)t]; ++kk)
-            if (cls_wide[(size_t)htab[(size_t)(((ntype + 1) & ~1) + 2 * (t * kmax + kk) + 1)]]) D.wide_mask |= 1u << kk;
+    // ---- code planes (DictArgs::plane_off): 2x2 blocks -- positions 2p, 2p+1 side by side in plane p; 3x3 -- plane k
+    const int64_t nbr_pad = ((int64_t)nbr + 15) & ~(int64_t)15;
     int64_t off = 0;
     for (int kk = 0; kk < kDictMaxK; ++kk) {
         D.plane_off[kk] = off;
-        // (a wide position: the plane of low halves, then the plane of high halves)
-        if (kk < kmax) off += (int64_t)(bs == 2 ? 8 : 24) * (((D.wide_mask >> kk) & 1u) ? 2 : 1) * (((int64_t)nbr + 15) & ~(int64_t)15);
+        if (bs == 2) {
+            if (2 * kk + 1 < kmax) off += 16 * nbr_pad;
+            else if (2 * kk < kmax) off += 8 * nbr_pad;
+        } else if (kk < kmax) {
+            off += 16 * nbr_pad;
+        }
     }
     D.codes.alloc((size_t)off, 64);
     D.bs = bs;
@@ -288,28 +302,21 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     D.nclass = ncls;
     D.kmax = kmax;
     D.lds_bytes = lds_bytes;
-    // bytes of codes one product reads: every stored block once, at its position's width
-    {
-        std::vector<int64_t> len_count((size_t)kmax + 1, 0);
-        // (block rows by length from the host's row pointers)
-        for (int32_t br = 0; br < nbr; ++br) len_count[(size_t)std::min(kmax, brp[(size_t)br + 1] - brp[(size_t)br])]++;
-        int64_t rows_ge = 0, bytes = 0;
-        for (int kk = kmax - 1; kk >= 0; --kk) {
-            rows_ge += len_count[(size_t)kk + 1];
-            bytes += rows_ge * (bs == 2 ? 8 : 24) * (((D.wide_mask >> kk) & 1u) ? 2 : 1);
-        }
-        D.code_bytes = bytes;
-    }
+    D.code_bytes = (int64_t)(bs == 2 ? 8 : 16) * nb;   // bytes of codes one product reads: every stored block once
     k::dict_encode_verify(D, browptr, bcol, slot.p, v0, v1, ldp, bad.p, s);
     SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
     SPK_HIP(hipStreamSynchronize(s));
     if (hbad) return refuse("a decoded value differs from the stored one", ntype, ncls);
     D.ok = true;
     if (verbose) {
-        int nw = 0;
-        for (int kk = 0; kk < kmax; ++kk) nw += (D.wide_mask >> kk) & 1u;
-        fprintf(stderr, "[spk] row types + codes: %d block rows, %d types (<= %d blocks, %d positions with 32-bit codes), %d classes of %d x %d, "
-                        "%d B of LDS, %.1f B of codes per block row\n", nbr, ntype, kmax, nw, ncls, bs, bs, lds_bytes, (double)D.code_bytes / nbr);
+        int wmax = 0;
+        for (int cl = 0; cl < ncls; ++cl) {
+            int tot = 0;
+            for (int e = 0; e < bb; ++e) tot += (hfld[(size_t)cl * bb + e] >> 8) & 255;
+            wmax = std::max(wmax, tot);
+        }
+        fprintf(stderr, "[spk] row types + codes: %d block rows, %d types (<= %d blocks), %d classes of %d x %d (<= %d bits of codes per block), "
+                        "%d B of LDS, %.1f B of codes per block row\n", nbr, ntype, kmax, ncls, bs, bs, wmax, lds_bytes, (double)D.code_bytes / nbr);
     }
 }
 

@@ -1,10 +1,9 @@
 #!/bin/bash
-# experiment: load-group size / occupancy of spmv_dict_kernel<2> (rebuilds spk_k_dict.o per variant on the box)
+# timing experiments on spmv_dict_kernel<2> (rebuilds the kernels per variant on the box; some variants compute wrong results)
 cd saddle_point_petsc_amd/csrc
-for cfg in "9 1" "5 1" "5 6" "3 1" "3 7"; do
-  set -- $cfg
-  touch spk_k_dict.hip
-  make -s XDEFS="-DSPK_DICT_G=$1 -DSPK_DICT_MINW=$2" > /dev/null 2>&1
-  echo "== G $1 minw $2"
-  (cd ../.. && timeout -k 10 200 python tools/kbench.py --grid 1024 --kernels spmv_dict --reps 200 2>&1 | grep spmv_dict | head -1)
+for cfg in "-DSPK_DICT_X_BASE" "-DSPK_DICT_X_NOFIELD" "-DSPK_DICT_X_ONESHIFT"; do
+  touch spk_k_dict.hip spk_k_resident.hip
+  make -s XDEFS="$cfg" > /dev/null 2>&1
+  echo "== $cfg"
+  (cd ../.. && timeout -k 10 200 python tools/kbench.py --grid 1024 --kernels spmv_dict,scale --reps 200 2>&1 | grep -E "^spmv|^scale" )
 done
