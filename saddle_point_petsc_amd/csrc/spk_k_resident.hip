@@ -575,10 +575,10 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                         const double2 *cb = cv + (size_t)e[g].y * 4;
                         const int32_t *fb = fl + (size_t)e[g].y * 4;
                         const u64 wd = cwd[k * T + t];
-                        s0 += dict_decode(dict_field(wd, 0ull, fb[0]), cb[0]) * xv[g][0];
-                        s0 += dict_decode(dict_field(wd, 0ull, fb[1]), cb[1]) * xv[g][1];
-                        s1 += dict_decode(dict_field(wd, 0ull, fb[2]), cb[2]) * xv[g][0];
-                        s1 += dict_decode(dict_field(wd, 0ull, fb[3]), cb[3]) * xv[g][1];
+                        s0 += dict_decode(dict_field2(wd, fb[0]), cb[0]) * xv[g][0];
+                        s0 += dict_decode(dict_field2(wd, fb[1]), cb[1]) * xv[g][1];
+                        s1 += dict_decode(dict_field2(wd, fb[2]), cb[2]) * xv[g][0];
+                        s1 += dict_decode(dict_field2(wd, fb[3]), cb[3]) * xv[g][1];
                     }
                 }
             }

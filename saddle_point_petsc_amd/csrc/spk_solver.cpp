@@ -252,9 +252,12 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
                 width = 2;
                 while ((double)((1ll << (width - 1)) - 1) < kabs) ++width;
             }
-            if (used[word] + width > 64) ++word;
-            if (word > (bs == 2 ? 0 : 1)) return refuse("the codes of a block class do not fit its word(s)", cl, used[0] + used[1] + width);
-            hfld[(size_t)i] = used[word] | (width << 8) | (word << 16);
+            // 2x2: two 32-bit halves of one word, a field inside one half (hardware bit-field extract); 3x3: two 64-bit words
+            const int cap = bs == 2 ? 32 : 64;
+            if (used[word] + width > cap) ++word;
+            if (word > 1) return refuse("the codes of a block class do not fit its word(s)", cl, used[0] + used[1] + width);
+            hfld[(size_t)i] = bs == 2 ? (int32_t)((uint32_t)used[word] | ((uint32_t)width << 8) | (word ? 0x80000000u : 0u))
+                                      : (used[word] | (width << 8) | (word << 16));
             used[word] += width;
             hcls[(size_t)2 * i + 1] = scale;
         }
