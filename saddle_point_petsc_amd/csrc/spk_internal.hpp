@@ -135,8 +135,9 @@ struct Bcsr3Dev {
 // rounding of a Jacobian formed from node coordinates (:96-128): the entries of A scatter by a few hundred ulps around a
 // handful of ideal values.  So A has a few dozen block CLASSES (blocks equal up to that noise) and a few dozen ROW TYPES
 // (sequences of (column offset, class) along a block row).  Stored per block row: one 16-bit type; per stored value: a
-// 16-bit (where a class scatters wider: 32-bit) integer k with  value = base[class][entry] + k 2^g[class][entry]  exactly.
-// The two small tables sit in LDS.  A product streams x, y and ~2.1 B per stored non-zero instead of 9 (blocked) / 12
+// two's-complement bit field k of the width its class entry needs with  value = base[class][entry] + k 2^g[class][entry]
+// exactly, a block's fields packed into one (2x2) / two (3x3) 64-bit words.
+// The small tables sit in LDS.  A product streams x, y and ~1.8 B per stored non-zero instead of 9 (blocked) / 12
 // (CSR) and forms the same products in the same order: bit-identical sums.  Found in the caller's CSR at KSPSetOperators
 // (hashing on the device, then EVERY value decoded and compared bit by bit); a matrix that does not fit (too many classes
 // or types, a row beyond kDictMaxK blocks, deviations that are not small multiples of one power of two or do not fit the
@@ -770,7 +771,8 @@ struct spk_ctx {
     int m_wide = 0;
     spk::DevBuf<int32_t> wide_rows;
     std::vector<int32_t> wide_rows_h;
-    spk::DevBuf<double> tmpb;  // scratch vector of the general block's D x0 products
+    spk::DevBuf<double> tmpb;  // scratch vector of the general block's D x0 / B^T y1 products
+    const double *bt_cached = nullptr;   // the multiplier vector whose B^T product tmpb holds (op_pc_apply -> op_mult)
 
     // halo plan
     std::vector<int> peers;
@@ -843,7 +845,7 @@ namespace spk {
 // y (+)= Ad x in the layout the context holds: row types + codes, 2x2 / 3x3 blocks or CSR (same sums in all of them)
 void a_mult(spk_ctx *c, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done, bool accumulate,
             const k::OffDiag *od, const k::GivensRider *rider = nullptr);
-void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool halo_done = false);
+void op_mult(spk_ctx *c, const double *x, double *y, const int32_t *done, bool halo_done = false, bool reuse_bt = false);
 void op_pc_apply(spk_ctx *c, const double *x, double *y, const int32_t *done);
 void pc_setup(spk_ctx *c, int pc_type, int schur_fact);
 void fgmres(spk_ctx *c, const double *b_dev, double *x_dev, const spk_opts &o, spk_result *res,

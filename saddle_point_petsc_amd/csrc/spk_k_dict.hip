@@ -7,10 +7,12 @@
 // i*h (:96-128), so the entries of A scatter by a few hundred ulps around a handful of ideal values (measured at 1024^2:
 // 34 185 distinct doubles, 7 ideal values; > 58 000 distinct 2x2 blocks at 256^2 already -- a dictionary of exact blocks
 // does not exist).  What repeats is the block up to that noise (a few dozen CLASSES) and the sequence of (column offset,
-// class) along a block row (a few dozen ROW TYPES).  Stored: one 16-bit type per block row, the two small tables (in LDS),
-// and per stored value a 16-bit integer k with   value = base[class][entry] + k * 2^g[class][entry]   EXACTLY (32-bit k
-// where a class scatters wider).  2.1 B per stored non-zero instead of 9 / 12; decoding is one integer conversion and one
-// FMA whose result is exact, so the products and their order -- hence every bit of the sums -- are those of the CSR loop.
+// class) along a block row (a few dozen ROW TYPES).  Stored: one 16-bit type per block row, the small tables (in LDS),
+// and per stored value an integer k with   value = base[class][entry] + k * 2^g[class][entry]   EXACTLY, as a
+// two's-complement bit field exactly as wide as its class entry needs (5 .. 19 bits at 1024^2), the fields of a block
+// packed into one 64-bit word (2x2) / two (3x3): 1.8 B per stored non-zero instead of 9 / 12.  Decoding is a bit-field
+// extract, one integer conversion and one FMA whose result is exact, so the products and their order -- hence every bit
+// of the sums -- are those of the CSR loop.
 // Nothing is assumed about the grid: classes and types are FOUND in the caller's CSR by hashing, the codes are verified
 // by decoding every value and comparing its bits, and a matrix that does not fit (too many classes / types, deviations
 // that are not small multiples of one power of two) keeps the blocked / CSR kernels.

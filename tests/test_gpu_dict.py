@@ -4,7 +4,7 @@ KSPSetOperators, bit-identical products, automatic fall-back.  Needs a real MI35
 The reference assembles the same element matrix for every element of a uniform grid
 (/root/reference/src/Discretization.c:25, :293-332) up to the rounding of a Jacobian formed from node coordinates
 (:96-128): A's entries scatter by a few hundred ulps around a handful of ideal values.  The layout stores a 16-bit row
-type per block row and a 16-bit integer deviation per value (value = base + k 2^g exactly) -- about 2 bytes per stored
+type per block row and an integer deviation per value as a bit field (value = base + k 2^g exactly) -- under 2 bytes per stored
 non-zero instead of 9 (blocked) or 12 (CSR) -- and forms the same products in the same order."""
 import numpy as np
 import pytest
