@@ -7,6 +7,7 @@ namespace spk {
 namespace k {
 
 constexpr int kDictChunk = kThreads;   // block rows per chunk: one per thread
+constexpr int kDict2Wgs = 256;         // pipelined 2x2 product: workgroups of a large launch (all co-resident; each pipelines its chunks)
 typedef int int2v __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
@@ -16,9 +17,10 @@ typedef unsigned long long u64;
 struct DictArgs {
     const uint16_t *tid;
     const int32_t *tab;
-    const double *cls;             // nclass x bs*bs x {base, 2^g}
+    const double *cls;             // (nclass + 1) x bs*bs x {base, 2^g}; the last one the NULL class: base 0, scale 0
     const int32_t *fld;            // nclass x bs*bs bit fields: shift | width << 8 | word << 16
     const unsigned char *codes;
+    const double *zpad;            // 32 bytes of zeros: what a position beyond a row's length gathers (with the null class)
     int32_t nbrows, ntype, nclass, kmax;
     int32_t nchunks, chunks_per_xcd, chunks_per_wg;
     int32_t tab_ints, cls_off, fld_off;   // ints of the type tables; byte offsets of the class and field tables in LDS
@@ -26,6 +28,7 @@ struct DictArgs {
     // plane p (16 bytes per block row: one full-width load; an odd last position: a plane of 8-byte words).
     // bs = 3: two words per block, plane k = position k (16 bytes per block row)
     int64_t plane_off[kDictMaxK];
+    int32_t uw[4];                 // 2x2, uniform field layout (DictDev::uniform): the widths of the four entries; uw[0] = 0: not uniform
 };
 
 // tables -> LDS (every workgroup; a few KB out of L2)
@@ -105,18 +108,21 @@ inline DictArgs dict_args(const DictDev &A, int *grid)
     d.cls = A.cls.p;
     d.fld = A.fld.p;
     d.codes = A.codes.p;
+    d.zpad = A.zpad.p;
+    for (int e = 0; e < 4; ++e) d.uw[e] = A.uniform ? A.uw[e] : 0;
     d.nbrows = A.nbrows;
     d.ntype = A.ntype;
     d.nclass = A.nclass;
     d.kmax = A.kmax;
     d.nchunks = (A.nbrows + kDictChunk - 1) / kDictChunk;
     // large systems: a few chunks per workgroup (the table copy is paid once per workgroup), about 2048 workgroups
-    d.chunks_per_wg = std::max(1, d.nchunks / 2048);
+    static const int wgs2 = [] { const char *e = getenv("SPK_DICT2_WGS"); return e && atoi(e) > 0 ? atoi(e) : kDict2Wgs; }();   // (developer knob)
+    d.chunks_per_wg = std::max(1, d.nchunks / (A.bs == 2 && A.kmax == 9 ? wgs2 : 2048));
     const int cpx = (d.nchunks + 7) / 8;
     d.chunks_per_xcd = (cpx + d.chunks_per_wg - 1) / d.chunks_per_wg * d.chunks_per_wg;
     d.tab_ints = ((A.ntype + 1) & ~1) + 2 * A.ntype * A.kmax;
     d.cls_off = (4 * d.tab_ints + 15) & ~15;
-    d.fld_off = d.cls_off + 16 * A.nclass * A.bs * A.bs;
+    d.fld_off = d.cls_off + 16 * (A.nclass + 1) * A.bs * A.bs;
     for (int k = 0; k < kDictMaxK; ++k) d.plane_off[k] = A.plane_off[k];
     *grid = 8 * (d.chunks_per_xcd / d.chunks_per_wg);
     return d;

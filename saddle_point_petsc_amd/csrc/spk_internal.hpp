@@ -149,13 +149,18 @@ struct DictDev {
     int64_t nblocks = 0;
     DevBuf<uint16_t> tid;          // type of every block row
     DevBuf<int32_t> tab;           // [ntype] lengths (padded to an even count), then ntype x kmax x {column offset, class}
-    DevBuf<double> cls;            // nclass x bs*bs x {base, 2^g}
-    DevBuf<int32_t> fld;           // nclass x bs*bs bit fields of the codes: shift | width << 8 | word << 16
+    DevBuf<double> cls;            // (nclass + 1) x bs*bs x {base, 2^g}: the last one is the NULL class (base 0, scale 0: decodes to +0)
+    DevBuf<int32_t> fld;           // (nclass + 1) x bs*bs bit fields of the codes (spk_dict.hpp: dict_field / dict_field2)
+    DevBuf<double> zpad;           // zeros: the x a position beyond a row's length gathers in the pipelined product
     DevBuf<unsigned char> codes;   // bs = 2: one 64-bit word per block, positions 2p / 2p+1 side by side in plane p (16 B per block
                                    // row; an odd last position: 8 B); bs = 3: two words per block, plane k = position k
     int64_t plane_off[kDictMaxK] = {};
     int64_t code_bytes = 0;        // bytes of codes a product reads (the planes without their padding rows)
     int32_t lds_bytes = 0;         // tables as laid out in LDS
+    // 2x2: every class has the SAME field layout (the widest need of any class per entry still fits: entries 0, 1 in the
+    // low half of the word, 2, 3 in the high half): the product kernel extracts without reading the field table
+    bool uniform = false;
+    int32_t uw[4] = {1, 1, 1, 1};
     bool ok = false;
 };
 

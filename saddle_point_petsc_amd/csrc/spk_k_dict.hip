@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const d
     // what does not depend on the tables is requested before they are copied
     int br = c0 * kDictChunk + (int)threadIdx.x;
     int tidn = br < d.nbrows ? (int)d.tid[br] : -1;
-    dict_load_lds(d, d.nclass * BS * BS, smem);
+    dict_load_lds(d, (d.nclass + 1) * BS * BS, smem);
     const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
     const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
     const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);
@@ -164,6 +164,149 @@ __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const d
     }
 }
 
+// ---------------------------------------------------------------------------
+// 2x2 blocks, row types of at most KM = 9 blocks (the 9-point stencil of the reference's Q1 grid, Discretization.c:25):
+// the same product, software-pipelined over the chunks of a workgroup.  The kernel above issues a chunk's loads, waits,
+// computes, and only then turns to the next chunk: with the four waves a SIMD holds, HBM idles while they decode and the
+// ALUs idle while they wait (PMC at 1024^2: SQ_WAIT_ANY 59 % of the wave cycles, ~10 us each of VALU and LDS work per CU
+// inside 33 us).  Here the loads of chunk c+1 -- code words, the gathers of x, y -- are in flight while chunk c is
+// decoded: two register stages, and NO branch around a load, so that the compiler's wait counts stay exact (a conditional
+// load makes every later wait a wait for everything).  A position beyond a row's length reads the zero pad with the NULL
+// class, whose decoded value is +0: the sums are unchanged, bit for bit; a chunk beyond the workgroup's range re-reads
+// the last block row and is not computed.
+// ---------------------------------------------------------------------------
+template <int KM, bool ACC>
+struct Dict2Stage {
+    u64 w[KM + 1];
+    double2 xv[KM];
+    int cls[KM];
+    double2 yv;
+};
+
+// (xr: x as a raw buffer of 16 * nbrows bytes -- a position beyond a row's length carries the offset 2^31 in the LDS copy
+// of its row type and the null class: the range check of the buffer load returns zeros, no select, no branch)
+template <int KM, bool ACC>
+__device__ __forceinline__ void dict2_issue(const DictArgs &d, __amdgpu_buffer_rsrc_t xr, const double *__restrict__ y,
+                                            const int2 *tent, int tc, int brr, Dict2Stage<KM, ACC> &S)
+{
+    static_assert(KM % 2 == 1, "an odd last position: its plane holds single words");
+#pragma unroll
+    for (int h = 0; h < KM / 2; ++h) {
+        const int4v r = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(d.codes + d.plane_off[h]) + brr);
+        S.w[2 * h] = (u64)(uint32_t)r.x | ((u64)(uint32_t)r.y << 32);
+        S.w[2 * h + 1] = (u64)(uint32_t)r.z | ((u64)(uint32_t)r.w << 32);
+    }
+    {
+        const int2v r = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(d.codes + d.plane_off[KM / 2]) + brr);
+        S.w[KM - 1] = (u64)(uint32_t)r.x | ((u64)(uint32_t)r.y << 32);
+    }
+    if (ACC) S.yv = reinterpret_cast<const double2 *>(y)[brr];
+    const int2 *te = tent + (size_t)tc * KM;
+    const uint32_t b16 = (uint32_t)brr * 16u;
+#pragma unroll
+    for (int g = 0; g < KM; ++g) {
+        const int2 e = te[g];
+        S.cls[g] = e.y;
+        const int4v r = __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(b16 + (uint32_t)e.x), 0, 0));
+        S.xv[g].x = __hiloint2double(r.y, r.x);
+        S.xv[g].y = __hiloint2double(r.w, r.z);
+    }
+}
+
+template <bool ACC, bool RIDE, bool BT, int KM, bool UNI>
+__global__ __launch_bounds__(kThreads) void spmv_dict2_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
+                                                              const int32_t *__restrict__ bt_rowptr,
+                                                              const int32_t *__restrict__ bt_colidx,
+                                                              const double *__restrict__ bt_val, const double *__restrict__ lam,
+                                                              OffDiag od, const int32_t *__restrict__ done, GivensRider gr)
+{
+#pragma clang fp contract(off)
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (RIDE && blockIdx.x == 0) {
+        givens_rider(gr, reinterpret_cast<double *>(smem));
+        return;
+    }
+    const int bx = (int)blockIdx.x - (RIDE ? 1 : 0);
+    const int c0 = ((bx & 7) * d.chunks_per_xcd + (bx >> 3) * d.chunks_per_wg);
+    const int c1 = min(min(c0 + d.chunks_per_wg, ((bx & 7) + 1) * d.chunks_per_xcd), d.nchunks);
+    if (c0 >= c1) return;
+    const int last = d.nbrows - 1;
+    auto rowof = [&](int ch) { return min(ch * kDictChunk + (int)threadIdx.x, last); };
+    // row types of the first two chunks: requested before the tables are copied
+    int tA = (int)d.tid[rowof(c0)];
+    int tB = (int)d.tid[rowof(c0 + 1)];
+    dict_load_lds(d, (d.nclass + 1) * 4, smem);
+    const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
+    int2 *tent = reinterpret_cast<int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
+    const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);
+    const int32_t *fl = reinterpret_cast<const int32_t *>(smem + d.fld_off);
+    // the LDS copy of the row types as the issue stage wants it: byte offsets of x; beyond a row's length an offset
+    // outside the buffer and the null class
+    for (int i = threadIdx.x; i < d.ntype * KM; i += kThreads) {
+        const int t = i / KM, k = i - t * KM;
+        int2 e = tent[i];
+        if (k < tlen[t]) e.x *= 16;
+        else e = make_int2((int)0x80000000u, d.nclass);
+        tent[i] = e;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, 16 * d.nbrows, 0x00020000);
+
+    Dict2Stage<KM, ACC> SA, SB;
+    auto compute = [&](int ch, const Dict2Stage<KM, ACC> &S) {
+        const int brc = ch * kDictChunk + (int)threadIdx.x;
+        double s[2] = {0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < KM; ++g) {
+            const double2 *cb = cv + (size_t)S.cls[g] * 4;
+            if (UNI) {
+                // one field layout for every class (DictArgs::uw): entries 0 / 2 at the bottom of the low / high half,
+                // 1 / 3 at the top -- one instruction each, no table read
+                const int lo = (int)(uint32_t)S.w[g], hi = (int)(uint32_t)(S.w[g] >> 32);
+                s[0] += dict_decode(__builtin_amdgcn_sbfe(lo, 0u, (unsigned)d.uw[0]), cb[0]) * S.xv[g].x;
+                s[0] += dict_decode(lo >> (32 - d.uw[1]), cb[1]) * S.xv[g].y;
+                s[1] += dict_decode(__builtin_amdgcn_sbfe(hi, 0u, (unsigned)d.uw[2]), cb[2]) * S.xv[g].x;
+                s[1] += dict_decode(hi >> (32 - d.uw[3]), cb[3]) * S.xv[g].y;
+            } else {
+                const int32_t *fb = fl + (size_t)S.cls[g] * 4;
+                s[0] += dict_decode(dict_field2(S.w[g], fb[0]), cb[0]) * S.xv[g].x;
+                s[0] += dict_decode(dict_field2(S.w[g], fb[1]), cb[1]) * S.xv[g].y;
+                s[1] += dict_decode(dict_field2(S.w[g], fb[2]), cb[2]) * S.xv[g].x;
+                s[1] += dict_decode(dict_field2(S.w[g], fb[3]), cb[3]) * S.xv[g].y;
+            }
+        }
+        if (brc > last) return;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t row = 2 * (int64_t)brc + r;
+            if (od.rowptr)
+                for (int k = od.rowptr[row]; k < od.rowptr[row + 1]; ++k) s[r] = __builtin_fma(od.val[k], od.xg[od.colidx[k]], s[r]);
+            if (BT)
+                for (int k = bt_rowptr[row]; k < bt_rowptr[row + 1]; ++k) s[r] = __builtin_fma(bt_val[k], lam[bt_colidx[k]], s[r]);
+            if (ACC) s[r] += r == 0 ? S.yv.x : S.yv.y;
+        }
+        double2 o;
+        o.x = s[0];
+        o.y = s[1];
+        reinterpret_cast<double2 *>(y)[brc] = o;
+    };
+
+    dict2_issue<KM, ACC>(d, xr, y, tent, tA, rowof(c0), SA);
+    tA = (int)d.tid[rowof(c0 + 2)];
+    for (int ch = c0;; ch += 2) {
+        // loads of the next chunk (and the row type of the one after it), then this chunk's arithmetic
+        dict2_issue<KM, ACC>(d, xr, y, tent, tB, rowof(ch + 1), SB);
+        tB = (int)d.tid[rowof(ch + 3)];
+        compute(ch, SA);
+        if (ch + 1 >= c1) break;
+        dict2_issue<KM, ACC>(d, xr, y, tent, tA, rowof(ch + 2), SA);
+        tA = (int)d.tid[rowof(ch + 4)];
+        compute(ch + 1, SB);
+        if (ch + 2 >= c1) break;
+    }
+}
+
 void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done,
                hipStream_t s, bool accumulate, const OffDiag *odp, const GivensRider *rider)
 {
@@ -194,7 +337,24 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
         if (rider) SPK_LAUNCH_DICT(BS, false, true, false);                                                                     \
         else SPK_LAUNCH_DICT(BS, false, false, false);                                                                          \
     }
-    if (A.bs == 2) { SPK_DISPATCH_DICT(2) }
+    if (A.bs == 2 && A.kmax == 9 && A.nbrows < (1 << 27)) {
+        // row types of the 9-point stencil: the pipelined kernel
+#pragma push_macro("SPK_LAUNCH_DICT")
+#undef SPK_LAUNCH_DICT
+#define SPK_LAUNCH_DICT(BS_, ACC, RIDE, BTF)                                                                                    \
+    do {                                                                                                                        \
+        if (A.uniform)                                                                                                          \
+            hipLaunchKernelGGL((spmv_dict2_kernel<ACC, RIDE, BTF, 9, true>), dim3(grid + nride), dim3(kThreads), lds, s, d, x,  \
+                               y, bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od,  \
+                               done, gr);                                                                                       \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((spmv_dict2_kernel<ACC, RIDE, BTF, 9, false>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, \
+                               y, bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od,  \
+                               done, gr);                                                                                       \
+    } while (0)
+        SPK_DISPATCH_DICT(2)
+#pragma pop_macro("SPK_LAUNCH_DICT")
+    } else if (A.bs == 2) { SPK_DISPATCH_DICT(2) }
     else { SPK_DISPATCH_DICT(3) }
 #undef SPK_DISPATCH_DICT
 #undef SPK_LAUNCH_DICT
@@ -218,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArg
     const int c0 = ((bx & 7) * d.chunks_per_xcd + (bx >> 3) * d.chunks_per_wg);
     const int c1 = min(min(c0 + d.chunks_per_wg, ((bx & 7) + 1) * d.chunks_per_xcd), d.nchunks);
     if (c0 >= c1) return;
-    dict_load_lds(d, d.nclass * BS * BS, smem);
+    dict_load_lds(d, (d.nclass + 1) * BS * BS, smem);
     const int32_t *tlen = reinterpret_cast<const int32_t *>(smem);
     const int2 *tent = reinterpret_cast<const int2 *>(smem + 4 * ((d.ntype + 1) & ~1));
     const double2 *cv = reinterpret_cast<const double2 *>(smem + d.cls_off);

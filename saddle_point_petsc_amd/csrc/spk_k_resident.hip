@@ -210,7 +210,7 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
     // the codes of this thread's block row: read once per cycle, decoded out of LDS in every product
     for (int k = 0; k < a.d.kmax; ++k)
         cwd[k * T + t] = active ? *dict_word_ptr<2>(a.d, const_cast<unsigned char *>(a.d.codes), k, br) : 0ull;
-    dict_load_lds(a.d, a.d.nclass * 4, smem);   // (ends with a barrier)
+    dict_load_lds(a.d, (a.d.nclass + 1) * 4, smem);   // (ends with a barrier)
     if (L->done || L->skip_iter) return;         // uniform: set by krylov_cycle_begin before this launch
     if (t < m) {
         lamV[t] = a.V0[a.nl + t];
@@ -573,12 +573,20 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
                     if (k0 + g < len) {
                         const int k = k0 + g;
                         const double2 *cb = cv + (size_t)e[g].y * 4;
-                        const int32_t *fb = fl + (size_t)e[g].y * 4;
                         const u64 wd = cwd[k * T + t];
-                        s0 += dict_decode(dict_field2(wd, fb[0]), cb[0]) * xv[g][0];
-                        s0 += dict_decode(dict_field2(wd, fb[1]), cb[1]) * xv[g][1];
-                        s1 += dict_decode(dict_field2(wd, fb[2]), cb[2]) * xv[g][0];
-                        s1 += dict_decode(dict_field2(wd, fb[3]), cb[3]) * xv[g][1];
+                        if (a.d.uw[0] > 0) {   // (uniform) one field layout for all classes: spk_k_dict.hip, spmv_dict2_kernel
+                            const int lo = (int)(uint32_t)wd, hi = (int)(uint32_t)(wd >> 32);
+                            s0 += dict_decode(__builtin_amdgcn_sbfe(lo, 0u, (unsigned)a.d.uw[0]), cb[0]) * xv[g][0];
+                            s0 += dict_decode(lo >> (32 - a.d.uw[1]), cb[1]) * xv[g][1];
+                            s1 += dict_decode(__builtin_amdgcn_sbfe(hi, 0u, (unsigned)a.d.uw[2]), cb[2]) * xv[g][0];
+                            s1 += dict_decode(hi >> (32 - a.d.uw[3]), cb[3]) * xv[g][1];
+                        } else {
+                            const int32_t *fb = fl + (size_t)e[g].y * 4;
+                            s0 += dict_decode(dict_field2(wd, fb[0]), cb[0]) * xv[g][0];
+                            s0 += dict_decode(dict_field2(wd, fb[1]), cb[1]) * xv[g][1];
+                            s1 += dict_decode(dict_field2(wd, fb[2]), cb[2]) * xv[g][0];
+                            s1 += dict_decode(dict_field2(wd, fb[3]), cb[3]) * xv[g][1];
+                        }
                     }
                 }
             }

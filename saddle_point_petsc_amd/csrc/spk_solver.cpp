@@ -159,12 +159,12 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
 {
     DictDev &D = c->Adict;
     D.ok = false;
-    D.tid.release(); D.tab.release(); D.cls.release(); D.fld.release(); D.codes.release();
+    D.tid.release(); D.tab.release(); D.cls.release(); D.fld.release(); D.codes.release(); D.zpad.release();
     const char *fmt = getenv("SPK_SPMV_FORMAT");
     if (fmt && (!strcmp(fmt, "csr") || !strcmp(fmt, "bcsr"))) return;
     static const bool verbose = getenv("SPK_DICT_VERBOSE") != nullptr;
     auto refuse = [&](const char *why, long a = 0, long b = 0) {
-        D.tid.release(); D.tab.release(); D.cls.release(); D.fld.release(); D.codes.release();
+        D.tid.release(); D.tab.release(); D.cls.release(); D.fld.release(); D.codes.release(); D.zpad.release();
         if (verbose) fprintf(stderr, "[spk] row types + codes refused: %s (%ld, %ld)\n", why, a, b);
     };
     hipStream_t s = c->stream;
@@ -219,39 +219,64 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     k::dict_hash_blocks(bs, v0, v1, ldp, nb, keys.p, rep.p, slot.p, ctl.p, k::kDictMaxBlk, s);
     const int ncls = classes();
     if (ncls <= 0) return refuse("block classes beyond the table", hctl[0], hctl[1]);
-    D.cls.alloc_raw((size_t)ncls * bb * 2, 8);
+    D.cls.alloc_raw((size_t)(ncls + 1) * bb * 2, 8);
     gexp.alloc_raw((size_t)ncls * bb, 8);
     dmax.alloc((size_t)ncls * bb, 8);
     SPK_HIP(hipMemsetAsync(gexp.p, 0x7f, sizeof(int32_t) * (size_t)ncls * bb, s));
     k::dict_class_stats(bs, v0, v1, ldp, nb, rep_d.p, ncls, slot2id_d.p, slot.p, D.cls.p, gexp.p, dmax.p, bad.p, s);   // slot[q] := class
     std::vector<int32_t> hg((size_t)ncls * bb);
     std::vector<unsigned long long> hm((size_t)ncls * bb);
-    std::vector<double> hcls((size_t)ncls * bb * 2);
+    std::vector<double> hcls((size_t)(ncls + 1) * bb * 2, 0.0);   // (the null class behind the found ones: zeros)
     int32_t hbad = 1;
     SPK_HIP(hipMemcpyAsync(hg.data(), gexp.p, sizeof(int32_t) * hg.size(), hipMemcpyDeviceToHost, s));
     SPK_HIP(hipMemcpyAsync(hm.data(), dmax.p, sizeof(unsigned long long) * hm.size(), hipMemcpyDeviceToHost, s));
-    SPK_HIP(hipMemcpyAsync(hcls.data(), D.cls.p, sizeof(double) * hcls.size(), hipMemcpyDeviceToHost, s));
+    SPK_HIP(hipMemcpyAsync(hcls.data(), D.cls.p, sizeof(double) * (size_t)ncls * bb * 2, hipMemcpyDeviceToHost, s));
     SPK_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof hbad, hipMemcpyDeviceToHost, s));
     SPK_HIP(hipStreamSynchronize(s));
     if (hbad) return refuse("a deviation from its class base is not exactly representable");
     // bit fields: entry (class, e) gets the width its largest deviation needs (two's complement), the fields of a block are
     // packed into one 64-bit word (2x2 blocks) or two (3x3: a field never straddles the words)
-    std::vector<int32_t> hfld((size_t)ncls * bb, 0);
+    std::vector<int32_t> hfld((size_t)(ncls + 1) * bb, 1 << 8);   // (null class: one bit at offset 0)
+    std::vector<int> hwid((size_t)ncls * bb, 1);
+    std::vector<double> hscale((size_t)ncls * bb, 1.0);
+    for (int i = 0; i < ncls * bb; ++i) {
+        if (hg[(size_t)i] < 0x7f000000) {   // some member deviates: granule = the finest bit in use
+            if (hg[(size_t)i] < -1000 || hg[(size_t)i] > 1000) return refuse("deviation granule out of range", i, hg[(size_t)i]);
+            const double scale = std::ldexp(1.0, hg[(size_t)i]);
+            double mag;
+            std::memcpy(&mag, &hm[(size_t)i], sizeof mag);
+            const double kabs = mag / scale;
+            if (!(kabs <= 1.0e9)) return refuse("a class entry scatters beyond 31-bit codes", i, (long)hg[(size_t)i]);
+            int width = 2;
+            while ((double)((1ll << (width - 1)) - 1) < kabs) ++width;
+            hwid[(size_t)i] = width;
+            hscale[(size_t)i] = scale;
+        }
+    }
+    // 2x2: one layout for all classes where the widest need per entry allows it (1024^2: 19 + 13 | 13 + 19 bits)
+    D.uniform = false;
+    if (bs == 2 && !getenv("SPK_DICT_NOUNIFORM")) {
+        int uw[4] = {1, 1, 1, 1};
+        for (int cl = 0; cl < ncls; ++cl)
+            for (int e = 0; e < 4; ++e) uw[e] = std::max(uw[e], hwid[(size_t)cl * 4 + e]);
+        if (uw[0] + uw[1] <= 32 && uw[2] + uw[3] <= 32) {
+            D.uniform = true;
+            for (int e = 0; e < 4; ++e) D.uw[e] = uw[e];
+            const uint32_t f[4] = {0u | ((uint32_t)uw[0] << 8), (uint32_t)(32 - uw[1]) | ((uint32_t)uw[1] << 8),
+                                   0x80000000u | ((uint32_t)uw[2] << 8), 0x80000000u | (uint32_t)(32 - uw[3]) | ((uint32_t)uw[3] << 8)};
+            for (int cl = 0; cl <= ncls; ++cl)   // (the null class too: any field of a zero word decodes to 0)
+                for (int e = 0; e < 4; ++e) hfld[(size_t)cl * 4 + e] = (int32_t)f[e];
+        }
+    }
     for (int cl = 0; cl < ncls; ++cl) {
         int used[2] = {0, 0}, word = 0;
         for (int e = 0; e < bb; ++e) {
             const int i = cl * bb + e;
-            double scale = 1.0;
-            int width = 1;
-            if (hg[(size_t)i] < 0x7f000000) {   // some member deviates: granule = the finest bit in use
-                if (hg[(size_t)i] < -1000 || hg[(size_t)i] > 1000) return refuse("deviation granule out of range", i, hg[(size_t)i]);
-                scale = std::ldexp(1.0, hg[(size_t)i]);
-                double mag;
-                std::memcpy(&mag, &hm[(size_t)i], sizeof mag);
-                const double kabs = mag / scale;
-                if (!(kabs <= 1.0e9)) return refuse("a class entry scatters beyond 31-bit codes", i, (long)hg[(size_t)i]);
-                width = 2;
-                while ((double)((1ll << (width - 1)) - 1) < kabs) ++width;
+            const double scale = hscale[(size_t)i];
+            const int width = hwid[(size_t)i];
+            if (D.uniform) {
+                hcls[(size_t)2 * i + 1] = scale;
+                continue;
             }
             // 2x2: two 32-bit halves of one word, a field inside one half (hardware bit-field extract); 3x3: two 64-bit words
             const int cap = bs == 2 ? 32 : 64;
@@ -264,7 +289,8 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
         }
     }
     SPK_HIP(hipMemcpyAsync(D.cls.p, hcls.data(), sizeof(double) * hcls.size(), hipMemcpyHostToDevice, s));
-    D.fld.alloc_raw((size_t)ncls * bb, 8);
+    D.fld.alloc_raw((size_t)(ncls + 1) * bb, 8);
+    D.zpad.alloc(8, 8);
     SPK_HIP(hipMemcpyAsync(D.fld.p, hfld.data(), sizeof(int32_t) * hfld.size(), hipMemcpyHostToDevice, s));
     // ---- row types
     DevBuf<int32_t> rslot;
@@ -276,7 +302,7 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     int kmax = 1;
     for (int32_t r : reps) kmax = std::max(kmax, brp[(size_t)r + 1] - brp[(size_t)r]);
     const int tab_ints = ((ntype + 1) & ~1) + 2 * ntype * kmax;
-    const int lds_bytes = ((((4 * tab_ints + 15) & ~15) + 16 * ncls * bb + 4 * ncls * bb) + 15) & ~15;
+    const int lds_bytes = ((((4 * tab_ints + 15) & ~15) + 16 * (ncls + 1) * bb + 4 * (ncls + 1) * bb) + 15) & ~15;
     if (lds_bytes > k::kDictLdsMax) return refuse("tables beyond the LDS budget", lds_bytes, ntype);
     D.tab.alloc((size_t)tab_ints, 8);
     D.tid.alloc_raw((size_t)nbr, 64);

@@ -150,6 +150,35 @@ def test_dictionary_in_the_solver(spk, oracle, monkeypatch):
     assert abs(idd["its"] - io["its"]) <= 1 and relerr(xd, xo) < 1e-7
 
 
+@pytest.mark.parametrize("mx,my", [(33, 33), (300, 200), (1024, 40)])
+def test_dictionary_per_class_fields(spk, oracle, monkeypatch, mx, my):
+    """Where the widest need of any class per block entry fits one common bit-field layout (what these grids do) the
+    pipelined product extracts without reading the field table; SPK_DICT_NOUNIFORM=1 keeps the per-class layout of larger
+    systems: the same bits from both, in the product, in the resident cycle and in a solve."""
+    A, f = spk.AssembleOperator_Laplace(mx, my)
+    B, g = spk.AssembleOperator_Constraints(mx, my)
+    rhs = np.concatenate([f, g])
+    x = _x(A.nrows, 9)
+    y_ref = oracle.spmv(A, x)
+
+    def run(c):
+        y = c.mult(x)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        z = c.mult(np.concatenate([x, [0.5, -0.25, 0.125, 1.0]]))     # (the B^T rows in the product's epilogue)
+        r5 = c.fgmres(rhs, rtol=1e-30, max_it=45, iteration_form=5)
+        r0 = c.fgmres(rhs, rtol=1e-30, max_it=45)                      # (AUTO: the resident cycle where it fits)
+        return y, z, r5, r0, c.iteration_form()
+    monkeypatch.delenv("SPK_DICT_NOUNIFORM", raising=False)
+    yu, zu, (xu5, iu5), (xu0, iu0), fu = _with_format(monkeypatch, spk, None, A, run)
+    monkeypatch.setenv("SPK_DICT_NOUNIFORM", "1")
+    yp, zp, (xp5, ip5), (xp0, ip0), fp = _with_format(monkeypatch, spk, None, A, run)
+    assert np.array_equal(yu, y_ref) and np.array_equal(yp, y_ref)
+    assert np.array_equal(zu, zp)
+    assert np.array_equal(iu5["history"], ip5["history"]) and np.array_equal(xu5, xp5)
+    assert fu == fp and np.array_equal(iu0["history"], ip0["history"]) and np.array_equal(xu0, xp0)
+
+
 def test_dictionary_row_slabs(spk, oracle, monkeypatch):
     """three logical ranks: every slab finds its own dictionary (rows at a cut lose their off-rank blocks to the halo
     part), the partitioned product equals the single-rank one bit for bit away from the cuts."""
