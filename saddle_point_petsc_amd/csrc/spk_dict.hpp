@@ -7,7 +7,7 @@ namespace spk {
 namespace k {
 
 constexpr int kDictChunk = kThreads;   // block rows per chunk: one per thread
-constexpr int kDict2Wgs = 256;         // pipelined 2x2 product: workgroups of a large launch (all co-resident; each pipelines its chunks)
+constexpr int kDict2Wgs = 512;         // pipelined 2x2 product: workgroups of a large launch (two per CU, all co-resident; each pipelines its chunks)
 typedef int int2v __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 

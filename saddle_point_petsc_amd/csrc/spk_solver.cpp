@@ -315,7 +315,11 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     // ---- code planes (DictArgs::plane_off): 2x2 blocks -- positions 2p, 2p+1 side by side in plane p; 3x3 -- plane k
     const int64_t nbr_pad = ((int64_t)nbr + 15) & ~(int64_t)15;
     int64_t off = 0;
+    // (the planes are read side by side, row r of each at the same time: a skew of 17 x 256 B per plane keeps planes whose
+    // size is a power of two -- 16 MiB each at 1024^2 -- from landing on one memory channel together)
+    static const int64_t skew = [] { const char *e = getenv("SPK_DICT_SKEW"); return e ? (int64_t)atoll(e) : (int64_t)(17 * 256); }();
     for (int kk = 0; kk < kDictMaxK; ++kk) {
+        off += kk ? skew : 0;
         D.plane_off[kk] = off;
         if (bs == 2) {
             if (2 * kk + 1 < kmax) off += 16 * nbr_pad;

@@ -1,12 +1,12 @@
 #!/bin/bash
-# developer: timing variants of the pipelined product
+# developer: plane skew and workgroup count of the pipelined product
 set -o pipefail
-cd saddle_point_petsc_amd/csrc
-for v in "-DSPK_X_NOGATHER -DSPK_X_NOCODES" "-DSPK_X_NOGATHER -DSPK_X_NOCODES -DSPK_X_NOLDS"; do
-  touch spk_k_dict.hip
-  make -j16 XDEFS="$v" > /dev/null 2>&1 || { echo "build failed $v"; exit 1; }
-  echo "variant [$v]"
-  for w in 256 512 768; do
-  (cd ../.. && echo "wgs $w" && SPK_DICT2_WGS=$w timeout -k 10 200 python tools/kbench.py --grid 1024 --kernels spmv_dict --reps 200 2>&1 | grep -E "^spmv")
+for sk in 1280 2304 4352 4608 12544 20736 1048832; do
+  for w in 512 768; do
+    echo -n "skew $sk wgs $w  "; SPK_DICT_SKEW=$sk SPK_DICT2_WGS=$w timeout -k 10 200 python tools/kbench.py --grid 1024 --kernels spmv_dict --reps 200 2>&1 | grep -E "^spmv"
   done
 done
+for sk in 4352 0; do for w in 256 512; do
+SPK_DICT_SKEW=$sk SPK_DICT2_WGS=$w timeout -k 10 200 python bench.py --steps 300 --warmup 30 --no-cpu-baseline > gpurun_out/bench_1024_s${sk}_w$w.json 2> gpurun_out/bench_1024.err
+done; done
+python tools/bench_summary.py
