@@ -329,7 +329,10 @@ def main():
     true_rnorm = float(np.sqrt(r2))
     # (below ~1e-11 of the initial residual the true residual sits on its round-off floor while the
     # recurrence keeps falling: both "converged", not comparable digit by digit)
-    residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= 1e-6 * max(true_rnorm, 1e-300) or
+    # (a restart beyond the default lengths: classical Gram-Schmidt without refinement lets the recurrence drift from the
+    # true residual inside a long cycle -- 5e-5 at restart 100, in the oracle as here; a wrong collective is off by O(1))
+    res_tol = 1e-6 if args.restart <= 62 else 1e-3
+    residual_ok = bool(abs(true_rnorm - info["rnorm"]) <= res_tol * max(true_rnorm, 1e-300) or
                        max(true_rnorm, info["rnorm"]) <= 1e-11 * info["rnorm0"])
 
     # ---- the same solver over WHOLE restart cycles (>= 3), whatever --steps says: a rate that does not

@@ -1283,13 +1283,16 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
     // keep one lane / one LDS slot per basis vector)
     const bool big = mk > k::kMaxNv - 2;
     if (big && c->bigdots.n < 2 * ((size_t)mk + 4)) c->bigdots.alloc(2 * ((size_t)mk + 4));   // first and refinement pass
-    const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR && !big;
+    // (a long restart keeps the head kernel -- VecScale + PCApply + the B^T part of the product in one pass, the product
+    // accumulating onto it, B D w' out of the last MAXPY chunk -- and only the Givens step is a launch of its own: its
+    // column no longer fits the head kernel's workgroup 0)
+    const bool fused = o.fused && c->bd.p && c->pc_type == SPK_PC_SCHUR;
     const int m = c->m;
     const int32_t nl = c->n_local;
     // the same head kernel without a constraint block: Jacobi on K = A (the reference as written,
     // SaddlePointProblem.c:66, and BASELINE config 2): VecScale + PCApply_Jacobi + deferred Givens
     const bool fusedj = o.fused && !fused && c->pc_type == SPK_PC_JACOBI && m == 0 && c->even_all && c->nonempty_all &&
-                        c->inner_sweeps == 0 && !big;
+                        c->inner_sweeps == 0;
     const bool head = fused || fusedj;
     const int nn = fused ? 1 + m : 1;  // norm (+ B D w') coming out of the last MAXPY of an iteration
     const int bpk = fused && c->bd_packed ? 1 : 0;   // B D as m/2 parity-interleaved planes
@@ -1614,9 +1617,9 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 if (!head_done) {
                     inhead = packed && c->comm->fused_halo(sr, c->xghost.p);   // ... or does the whole exchange
                     k::fused_head(Vj(loc), nrmbuf(loc + 1), w1side, c->dinv.p, bdp, ld, c->shat.p, c->gram.p,
-                                  c->schur_fact, nl, m, Zj(loc), w, c->ka, loc - 1, dotsbuf(loc + 1), done, s,
+                                  c->schur_fact, nl, m, Zj(loc), w, c->ka, big ? -1 : loc - 1, dotsbuf(loc + 1), done, s,
                                   packed ? &sr : nullptr, bpk);
-                    last = loc;
+                    last = big ? -1 : loc;
                     if (single) k::copy_small(w + nl, wl(loc), m, done, s);
                 }
                 // w += A z0 (halo exchange, then diagonal and off-rank columns in ONE kernel)
@@ -1632,8 +1635,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::SendRanges sr = c->send_ranges;
                     inhead = sr.n > 0 && c->comm->fused_halo(sr, c->xghost.p);
                     k::fused_head(Vj(loc), nrmbuf(loc + 1), nullptr, c->dinv.p, nullptr, ld, nullptr, nullptr, SPK_SCHUR_LOWER,
-                                  nl, 0, Zj(loc), nullptr, c->ka, loc - 1, dotsbuf(loc + 1), done, s, inhead ? &sr : nullptr);
-                    last = loc;
+                                  nl, 0, Zj(loc), nullptr, c->ka, big ? -1 : loc - 1, dotsbuf(loc + 1), done, s, inhead ? &sr : nullptr);
+                    last = big ? -1 : loc;
                 }
                 op_mult(c, Zj(loc), w, done, inhead);    // w = A z_j (halo inside, unless the head kernel did it)
             } else {
@@ -1685,7 +1688,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                 for (int v0 = 0; v0 <= loc; v0 += 40) {
                     const int cnt = std::min(40, loc + 1 - v0);
                     const bool lastc = v0 + 40 > loc;
-                    k::maxpy(Vj(v0), ld, cnt, nullptr, db + v0, -1.0, w, N, n_dot, c->fin(lastc ? nb : nullptr), done, s);
+                    k::maxpy(Vj(v0), ld, cnt, nullptr, db + v0, -1.0, w, N, n_dot, c->fin(lastc ? nb : nullptr), done, s,
+                             lastc ? bdp : nullptr, ld, nl, m, lastc && fused ? w1side : nullptr, nullptr, bpk);
                 }
                 c->comm->allreduce_sum(nb, nn, s);
                 if (o.cgs_refine != SPK_REFINE_NEVER) {
@@ -1702,7 +1706,8 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     for (int v0 = 0; v0 <= loc; v0 += 40) {
                         const int cnt = std::min(40, loc + 1 - v0);
                         const bool lastc = v0 + 40 > loc;
-                        k::maxpy(Vj(v0), ld, cnt, nullptr, db2 + v0, -1.0, w, N, n_dot, c->fin(lastc ? nrm2b : nullptr), skip, s);
+                        k::maxpy(Vj(v0), ld, cnt, nullptr, db2 + v0, -1.0, w, N, n_dot, c->fin(lastc ? nrm2b : nullptr), skip, s,
+                                 lastc ? bdp : nullptr, ld, nl, m, lastc && fused ? w1side : nullptr, nullptr, bpk);
                     }
                     c->comm->allreduce_sum(nrm2b, nn, s);
                     k::krylov_refine_merge(c->ka, loc, db, db2, nb, nrm2b, nn, s);
@@ -1729,10 +1734,11 @@ void fgmres(spk_ctx *c, const double *b, double *x, const spk_opts &o, spk_resul
                     k::krylov_refine_merge(c->ka, loc, db, sm2, nb, nrm2b, nn, s);
                 }
             }
-            if (!head) {
-                // Hessenberg column, Givens, convergence -- on the device; then v_{j+1} = w / ||w||
+            if (!head || big) {
+                // Hessenberg column, Givens, convergence -- on the device; then v_{j+1} = w / ||w|| (the head kernel of the
+                // next iteration does that scaling where there is one)
                 k::krylov_givens(c->ka, loc, db, nb, s);
-                k::scale_dev(w, N, inv_tt, done, s);
+                if (!head) k::scale_dev(w, N, inv_tt, done, s);
             }
             if (o.check_every > 0 && (loc + 1) % o.check_every == 0 && loc + 1 < mk) {
                 SPK_HIP(hipMemcpyAsync(&st, c->kst.p, sizeof st, hipMemcpyDeviceToHost, s));

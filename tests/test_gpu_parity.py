@@ -311,8 +311,8 @@ def test_restart_lengths(spk, oracle, restart, single):
 @pytest.mark.parametrize("restart,orthog", [(63, 0), (100, 0), (200, 1), (500, 0)])
 def test_long_restart_cycles(spk, oracle, restart, orthog):
     """-ksp_gmres_restart beyond the 62 of the fused kernels (PETSc takes any length through KSPSetFromOptions,
-    SaddlePointProblem.c:67): the step-by-step path with Gram-Schmidt in chunks of 40 vectors, the Givens step and the
-    back substitution from their large forms.  One cycle can hold the whole solve here (restart 500 > iterations)."""
+    SaddlePointProblem.c:67): Gram-Schmidt in chunks of 40 vectors, the Givens step and the back substitution from their
+    large forms.  One cycle can hold the whole solve here (restart 500 > iterations)."""
     A, f = spk.AssembleOperator_Laplace(24, 20)
     B, g = spk.AssembleOperator_Constraints(24, 20)
     rhs = np.concatenate([f, g])
@@ -321,6 +321,14 @@ def test_long_restart_cycles(spk, oracle, restart, orthog):
         c.set_block(spk.BLOCK_A10, B)
         c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
         x, info = c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=4000, orthog=orthog)
+        # round 3: a long restart keeps the head kernel (VecScale + PCApply + B^T part in one pass, B D w' out of the last
+        # MAXPY chunk); only the Givens step is a launch of its own.  fused=0: the step-by-step launches, the same iterates
+        assert c.iteration_form()[0] == 1
+        xs, infos = c.fgmres(rhs, restart=restart, rtol=1e-10, max_it=4000, orthog=orthog, fused=0)
+        assert c.iteration_form()[0] == -1
+        ks = min(len(info["history"]), len(infos["history"]), 150) - 1
+        assert abs(info["its"] - infos["its"]) <= 2 and np.allclose(info["history"][:ks], infos["history"][:ks], rtol=1e-5)
+        assert relerr(x, xs) < 1e-7
         refined = {}
         if orthog == 0 and restart <= 200:
             # -ksp_gmres_cgs_refinement_type on a long restart (round 3: the second pass runs in the same chunks)
@@ -341,6 +349,24 @@ def test_long_restart_cycles(spk, oracle, restart, orthog):
     assert relerr(x, xo) < 1e-7
     r = np.linalg.norm(rhs - oracle.apply_K(A, B, x))
     assert r <= 1.01e-10 * np.linalg.norm(rhs) and r == pytest.approx(info["rnorm"], rel=1e-4)
+
+
+def test_long_restart_jacobi_head_path(spk, oracle):
+    """The same on the Jacobi head path (K = A, the reference as written, SaddlePointProblem.c:66): restart 90."""
+    A, f = spk.AssembleOperator_Laplace(40, 28)
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.pc_setup(spk.PC_JACOBI)
+        x, info = c.fgmres(f, restart=90, rtol=1e-10, max_it=4000)
+        assert c.iteration_form()[0] == 1
+        xr, ir = c.fgmres(f, restart=90, rtol=1e-10, max_it=4000, cgs_refine=1)
+    xo, io = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, restart=90, rtol=1e-10, max_it=4000)
+    xro, iro = oracle.fgmres(A, f, pc_type=oracle.PC_JACOBI, restart=90, rtol=1e-10, max_it=4000, refine=1)
+    for (xa, ia), (xb, ib) in (((x, info), (xo, io)), ((xr, ir), (xro, iro))):
+        assert ia["reason"] == ib["reason"] == 2 and abs(ia["its"] - ib["its"]) <= 2
+        k = min(len(ia["history"]), len(ib["history"]), 150) - 1
+        assert np.allclose(ia["history"][:k], ib["history"][:k], rtol=1e-5)
+        assert relerr(xa, xb) < 1e-7
 
 
 def test_single_reduction_jacobi_head_path(spk, oracle):
