@@ -75,8 +75,9 @@ enum { SPK_CONVERGED_RTOL = 2, SPK_CONVERGED_ATOL = 3, SPK_CONVERGED_ITS = 4,
  * exposes through KSPSetFromOptions (SaddlePointProblem.c:67).  Fill with
  * spk_default_opts() first (PETSc defaults). */
 typedef struct spk_opts {
-    int32_t restart;        /* -ksp_gmres_restart            (30); 1..1022 -- up to 62 on the fused kernels, beyond
-                               on the step-by-step path (Gram-Schmidt in chunks of 40 vectors) */
+    int32_t restart;        /* -ksp_gmres_restart            (30); 1..1022 -- restart + m <= 62: the fused iteration forms;
+                               beyond: the head kernel stays, Gram-Schmidt runs in chunks of 40 vectors and the
+                               Givens step is a launch of its own */
     int32_t max_it;         /* -ksp_max_it                   (10000) */
     double rtol;            /* -ksp_rtol                     (1e-5)  */
     double abstol;          /* -ksp_atol                     (1e-50) */
@@ -271,7 +272,8 @@ int spk_fgmres(spk_ctx *ctx, const double *b, double *x, int mem, const spk_opts
 
 /* How the LAST spk_fgmres on ctx launched its iterations: *form = the SPK_ITER_* actually run (AUTO resolved; options
  * the chosen form does not cover fall back, see spk_opts.iteration_form), or -1 for the step-by-step path (PCApply and
- * MatMult as launches of their own: unfused preconditioners, FP32 inner sweeps, restart > 62, MGS, CGS refinement);
+ * MatMult as launches of their own: unfused preconditioners, FP32 inner sweeps, general constraint blocks; a restart
+ * beyond 62, MGS or CGS refinement on a fusable preconditioner report SPK_ITER_FOUR_LAUNCH: the head kernel runs);
  * *single_reduce = 1 when the single-reduction mode ran.  For byte models (bench.py). */
 int spk_get_iteration_form(const spk_ctx *ctx, int32_t *form, int32_t *single_reduce);
 
@@ -292,14 +294,17 @@ int spk_get_sizes(const spk_ctx *ctx, int64_t *n_global, int32_t *n_local, int32
  * their pattern and columns pair up, as for a dof-2 DMDA; SPK_SPMV_FORMAT=csr forces CSR).
  * layout_bytes = bytes one SpMV reads and writes in that layout (matrix + x + y). */
 int spk_get_spmv_info(const spk_ctx *ctx, int32_t *format, int64_t *layout_bytes);
-/* Formats 3 / 4: ROW-PATTERN DICTIONARY over the 2x2 / 3x3 blocks (the default wherever it exists).  On the reference's
- * uniform grid (Discretization.c:25; one element matrix for all elements, :293-332) A holds a handful of distinct blocks
- * in a few dozen distinct block-row sequences; they are found in the caller's CSR at spk_set_block (hashing + a bitwise
- * verification pass; nothing is assumed about the grid), kept in LDS, and a product then streams x, y and two bytes per
- * block row -- same products, same order, same bits as the CSR loop.  Matrices whose rows do not repeat keep formats
- * 0..2; SPK_SPMV_FORMAT=bcsr (or csr) switches the dictionary off.
+/* Formats 3 / 4: ROW TYPES + DEVIATION CODES over the 2x2 / 3x3 blocks (the default wherever the layout exists).  On the
+ * reference's uniform grid (Discretization.c:25; one element matrix for all elements, :293-332) the assembled entries
+ * scatter by rounding noise around a handful of ideal values (:96-128: a Jacobian formed from coordinates): A holds a few
+ * dozen block CLASSES (blocks equal up to that noise) in a few dozen ROW TYPES (sequences of (column offset, class)).
+ * They are found in the caller's CSR at spk_set_block (hashing, then EVERY value decoded and compared bit for bit;
+ * nothing is assumed about the grid).  Stored: two bytes of type per block row and per value an integer k with
+ * value = base + k 2^g exactly, as a bit field of the width its class entry needs (one 64-bit word per 2x2 block, two
+ * per 3x3 block) -- same products, same order, same bits as the CSR loop.  Matrices that do not fit keep formats 0..2;
+ * SPK_SPMV_FORMAT=bcsr (or csr) switches the layout off, SPK_DICT_VERBOSE=1 reports what was found or why not.
  * Byte models of one product y = A x on this rank's diagonal block in the three layouts (0 where a layout does not
- * exist), and the dictionary's size (distinct block rows, distinct blocks). */
+ * exist), and the layout's size (patterns = row types, blocks = block classes). */
 int spk_get_spmv_models(const spk_ctx *ctx, int64_t *csr_bytes, int64_t *blocked_bytes, int64_t *dict_bytes,
                         int32_t *patterns, int32_t *blocks);
 

@@ -14,6 +14,7 @@ python3 $R/bench.py --grid 256 --no-cpu-baseline > $out/${tag}_bench_256_schur.j
 python3 $R/bench.py --grid 512 --no-cpu-baseline > $out/${tag}_bench_512.json 2> $out/bench_512.err
 python3 $R/bench.py --grid 1024 --grid-y 256 --no-cpu-baseline > $out/${tag}_bench_slab_1of4.json 2> $out/bench_slab4.err
 python3 $R/bench.py --grid 1024 --grid-y 512 --no-cpu-baseline > $out/${tag}_bench_slab_1of2.json 2> $out/bench_slab2.err
+python3 $R/bench.py --restart 100 --no-cpu-baseline > $out/${tag}_bench_restart100.json 2> $out/bench_r100.err
 python3 $R/bench.py --steps 60 --warmup 10 --dim 3 --grid 256 --grid-y 256 --grid-z 32 --pc jacobi --inner-sweeps 3 --no-cpu-baseline > $out/${tag}_bench_3d_slab_256x256x32_fp32_inner.json 2> $out/bench_3d.err
 python3 $R/bench.py --steps 60 --warmup 10 --dim 3 --grid 256 --grid-y 256 --grid-z 32 --no-cpu-baseline > $out/${tag}_bench_3d_slab_256x256x32_schur.json 2> $out/bench_3ds.err
 python3 $R/bench.py --steps 60 --warmup 10 --dim 3 --grid 96 --no-cpu-baseline > $out/${tag}_bench_3d_96_moments.json 2> $out/bench_3d96.err

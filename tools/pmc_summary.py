@@ -50,7 +50,8 @@ tr["workload"] = "1024x1024 grid A-block SpMV"
 for key, pat in (("csr", "spmv_stream"), ("bcsr2x2", "spmv_bcsr_kernel"), ("dict2x2", "spmv_dict2_kernel")):
     # (first the variant the iteration launches: ACC = true, RIDE = true)
     sp = sorted((k for k in out["kernels"] if pat in k),
-                key=lambda k: (0 if ("true, true, true>" in k or "true, true, true, false>" in k or "<2, true, true, false>" in k) else 1, k))
+                key=lambda k: (0 if ("true, true, true>" in k or "true, true, true, false>" in k or "<2, true, true, false>" in k or
+                                      "<true, true, false, 9" in k) else 1, k))
     if sp:
         tr["hbm_bytes_per_launch_" + key] = out["kernels"][sp[0]]["hbm_bytes_corrected"]
         tr["source_" + key] = f"profiles/{tag}_pmc_summary.json ({sp[0]})"
