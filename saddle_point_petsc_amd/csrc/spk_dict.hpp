@@ -28,6 +28,7 @@ struct DictArgs {
     // plane p (16 bytes per block row: one full-width load; an odd last position: a plane of 8-byte words).
     // bs = 3: two words per block, plane k = position k (16 bytes per block row)
     int64_t plane_off[kDictMaxK];
+    int32_t strad;                 // 2x2: some field lies across the halves of its word (dict_field2)
     int32_t uw[4];                 // 2x2, uniform field layout (DictDev::uniform): the widths of the four entries; uw[0] = 0: not uniform
 };
 
@@ -85,6 +86,19 @@ __device__ __forceinline__ int dict_field2(u64 w, int fd)
     const int src = (hi & mask) | (lo & ~mask);      // (one v_bfi_b32)
     return __builtin_amdgcn_sbfe(src, (unsigned)fd, (unsigned)(fd >> 8));   // v_bfe_i32 reads 5 bits of offset and of width
 }
+// A class whose four widths allow no packing inside the halves (2048^2: 20 + 14 + 14 + 13 bits) gets its fields back to
+// back in the 64 bits; one that lies ACROSS the halves carries kDictAcross and its shift from bit 0 of the word in bits
+// 0-5.  strad (uniform): the layout holds such fields at all -- the plain kernels honour it, the pipelined product and the
+// resident cycle are not launched on such a layout.
+constexpr int kDictAcross = 1 << 30;
+__device__ __forceinline__ int dict_field2(u64 w, int fd, bool strad)
+{
+    if (strad && (fd & kDictAcross)) {
+        const int sh = fd & 63, wd = (fd >> 8) & 31;
+        return (int)((long long)(w << (64 - sh - wd)) >> (64 - wd));
+    }
+    return dict_field2(w, fd);
+}
 // value = base + k * 2^g: both terms exact, the sum representable (it is the stored value): exact under any rounding
 __device__ __forceinline__ double dict_decode(int code, double2 bs)
 {
@@ -109,6 +123,7 @@ inline DictArgs dict_args(const DictDev &A, int *grid)
     d.fld = A.fld.p;
     d.codes = A.codes.p;
     d.zpad = A.zpad.p;
+    d.strad = A.straddle ? 1 : 0;
     for (int e = 0; e < 4; ++e) d.uw[e] = A.uniform ? A.uw[e] : 0;
     d.nbrows = A.nbrows;
     d.ntype = A.ntype;

@@ -143,6 +143,7 @@ struct Bcsr3Dev {
 // or types, a row beyond kDictMaxK blocks, deviations that are not small multiples of one power of two or do not fit the
 // words, tables beyond the LDS budget) keeps the plain blocked layout.
 constexpr int kDictMaxK = 32;      // blocks per block row
+namespace k { constexpr int kDictAcrossHost = 1 << 30; }   // = kDictAcross (spk_dict.hpp, device side)
 struct DictDev {
     int bs = 0;
     int32_t nbrows = 0, ntype = 0, nclass = 0, kmax = 0;
@@ -161,6 +162,7 @@ struct DictDev {
     // low half of the word, 2, 3 in the high half): the product kernel extracts without reading the field table
     bool uniform = false;
     int32_t uw[4] = {1, 1, 1, 1};
+    bool straddle = false;         // 2x2: some class has a field across the halves of its word (spk_dict.hpp)
     bool ok = false;
 };
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const d
                     for (int r = 0; r < BS; ++r)
 #pragma unroll
                         for (int j = 0; j < BS; ++j)
-                            s[r] += dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j]) : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * xv[g][j];
+                            s[r] += dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j], d.strad != 0) : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * xv[g][j];
                 }
             }
         }
@@ -337,7 +337,7 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
         if (rider) SPK_LAUNCH_DICT(BS, false, true, false);                                                                     \
         else SPK_LAUNCH_DICT(BS, false, false, false);                                                                          \
     }
-    if (A.bs == 2 && A.kmax == 9 && A.nbrows < (1 << 27)) {
+    if (A.bs == 2 && A.kmax == 9 && A.nbrows < (1 << 27) && !A.straddle) {
         // row types of the 9-point stencil: the pipelined kernel
 #pragma push_macro("SPK_LAUNCH_DICT")
 #undef SPK_LAUNCH_DICT
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArg
                     for (int r = 0; r < BS; ++r)
 #pragma unroll
                         for (int j = 0; j < BS; ++j)
-                            s[r] = (s[r] + ((float)dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j]) : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * yv[g][j]));
+                            s[r] = (s[r] + ((float)dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j], d.strad != 0) : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * yv[g][j]));
                 }
             }
         }
@@ -687,8 +687,8 @@ __global__ __launch_bounds__(kThreads) void dict_encode_kernel(DictArgs d, const
                 const double base = d.cls[2 * (id * BS * BS + e)], sc = d.cls[2 * (id * BS * BS + e) + 1];
                 const int fd = d.fld[id * BS * BS + e];
                 // (2x2: offset inside a 32-bit half, bit 31 = the high half; 3x3: shift inside a 64-bit word, word number)
-                const int wd = (fd >> 8) & 255;
-                const int sh = BS == 2 ? (fd & 31) + ((fd >> 31) & 1) * 32 : (fd & 255);
+                const int wd = BS == 2 ? (fd >> 8) & 31 : (fd >> 8) & 255;
+                const int sh = BS == 2 ? ((fd & kDictAcross) ? (fd & 63) : (fd & 31) + ((fd >> 31) & 1) * 32) : (fd & 255);
                 const int wi = BS == 2 ? 0 : (fd >> 16);
                 const double kq = (blk_val<BS>(v0, v1, ldp, q0 + k, r, j) - base) / sc;
                 const long long kk = (long long)rint(kq);
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(kThreads) void dict_verify_kernel(DictArgs d, const
         for (int r = 0; r < BS; ++r)
 #pragma unroll
             for (int j = 0; j < BS; ++j)
-                ok = ok && __double_as_longlong(dict_decode(BS == 2 ? dict_field2(w0, fb[r * BS + j]) : dict_field(w0, w1, fb[r * BS + j]), cb[r * BS + j])) ==
+                ok = ok && __double_as_longlong(dict_decode(BS == 2 ? dict_field2(w0, fb[r * BS + j], d.strad != 0) : dict_field(w0, w1, fb[r * BS + j]), cb[r * BS + j])) ==
                                __double_as_longlong(blk_val<BS>(v0, v1, ldp, q0 + k, r, j));
     }
     if (!ok) *bad = 1;

@@ -664,7 +664,7 @@ size_t resident_lds_bytes(const DictDev &A, int T)
 // does the resident cycle kernel take this system?  (np: planes of B D)
 bool resident_fits(const DictDev &A, int num_cus, int mk, int np)
 {
-    if (!A.ok || A.bs != 2 || num_cus < 1 || A.nbrows < 1) return false;
+    if (!A.ok || A.bs != 2 || A.straddle || num_cus < 1 || A.nbrows < 1) return false;
     const int G = (int)std::min<int64_t>(res_grid_cap(num_cus), ((int64_t)A.nbrows + 63) / 64);
     const int rpw = (A.nbrows + G - 1) / G;
     if (rpw > 512 || mk > kResMaxV - 1 || mk < 2 || np > 4) return false;

@@ -268,8 +268,28 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
                 for (int e = 0; e < 4; ++e) hfld[(size_t)cl * 4 + e] = (int32_t)f[e];
         }
     }
+    D.straddle = false;
     for (int cl = 0; cl < ncls; ++cl) {
         int used[2] = {0, 0}, word = 0;
+        if (bs == 2 && !D.uniform) {
+            // no packing of this class's fields inside the halves, but 64 bits suffice: back to back, a field across
+            // the halves flagged (the plain kernels extract it with 64-bit shifts)
+            const int *w = &hwid[(size_t)cl * 4];
+            const bool fits_halves = w[0] + w[1] <= 32 && w[2] + w[3] <= 32;
+            if (!fits_halves && w[0] + w[1] + w[2] + w[3] <= 64) {
+                int sh = 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int i = cl * 4 + e;
+                    const bool across = sh < 32 && sh + w[e] > 32;
+                    hfld[(size_t)i] = across ? (int32_t)((uint32_t)sh | ((uint32_t)w[e] << 8) | (uint32_t)k::kDictAcrossHost)
+                                             : (int32_t)((uint32_t)(sh & 31) | ((uint32_t)w[e] << 8) | (sh >= 32 ? 0x80000000u : 0u));
+                    D.straddle = D.straddle || across;
+                    sh += w[e];
+                    hcls[(size_t)2 * i + 1] = hscale[(size_t)i];
+                }
+                continue;
+            }
+        }
         for (int e = 0; e < bb; ++e) {
             const int i = cl * bb + e;
             const double scale = hscale[(size_t)i];
@@ -350,7 +370,15 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
             wmax = std::max(wmax, tot);
         }
         fprintf(stderr, "[spk] row types + codes: %d block rows, %d types (<= %d blocks), %d classes of %d x %d (<= %d bits of codes per block), "
-                        "%d B of LDS, %.1f B of codes per block row\n", nbr, ntype, kmax, ncls, bs, bs, wmax, lds_bytes, (double)D.code_bytes / nbr);
+                        "%d B of LDS, %.1f B of codes per block row%s\n", nbr, ntype, kmax, ncls, bs, bs, wmax, lds_bytes, (double)D.code_bytes / nbr,
+                D.uniform ? ", one field layout for all classes" : "");
+        fprintf(stderr, "[spk]   widest need per block entry:");
+        for (int e = 0; e < bb; ++e) {
+            int w = 1;
+            for (int cl = 0; cl < ncls; ++cl) w = std::max(w, hwid[(size_t)cl * bb + e]);
+            fprintf(stderr, " %d", w);
+        }
+        fprintf(stderr, "\n");
     }
 }
 

@@ -100,6 +100,36 @@ def test_dictionary_takes_perturbed_entries(spk, oracle, monkeypatch):
     assert np.array_equal(y, oracle.spmv(A2, x))
 
 
+def test_dictionary_fields_across_the_halves(spk, oracle, monkeypatch):
+    """A class whose four widths allow no packing inside the 32-bit halves of its word but fit 64 bits (what the 2048^2
+    grid brings: 20 + 14 + 14 + 13) keeps the layout with a field across the halves: the plain kernels extract it with
+    64-bit shifts; the pipelined product and the resident cycle stand back.  Here: the first diagonal entry of every
+    diagonal block scattered over 2^23 granules of 2^-46 by hand."""
+    A, f = spk.AssembleOperator_Laplace(48, 40)
+    B, g = spk.AssembleOperator_Constraints(48, 40)
+    val = A.val.copy()
+    rng = np.random.default_rng(11)
+    rows = np.repeat(np.arange(A.nrows), np.diff(A.rowptr))
+    big = np.abs(val) > 1e-3
+    diag = big & (rows == A.colidx) & (rows % 2 == 0)      # entry (0, 0) of the diagonal blocks: 24 bits of codes
+    val[diag] += rng.integers(-2**22, 2**22, int(diag.sum())) * 2.0**-46
+    A2 = spk.CSR(A.rowptr, A.colidx, val, A.ncols)
+    x = _x(A.nrows, 8)
+    rhs = np.concatenate([f, g])
+
+    def run(c):
+        y = c.mult(x)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        return c.spmv_info()["format"], y, c.fgmres(rhs, rtol=1e-30, max_it=40), c.iteration_form()[0]
+    fmt, y, (xs, info), form = _with_format(monkeypatch, spk, None, A2, run)
+    fb, yb, (xb, ib), formb = _with_format(monkeypatch, spk, "bcsr", A2, run)
+    assert fmt == "dict2x2" and fb == "bcsr2x2"
+    assert np.array_equal(y, oracle.spmv(A2, x)) and np.array_equal(y, yb)
+    assert form == 5 and formb == 5            # (no resident cycle on such a layout)
+    assert np.array_equal(info["history"], ib["history"]) and np.array_equal(xs, xb)
+
+
 def test_dictionary_refuses_matrices_without_repetition(spk, oracle, monkeypatch):
     """every block different (random values on the grid's pattern): more than 1024 block classes -> the blocked layout
     stays, results unchanged; and too many distinct ROW TYPES with few block classes likewise."""
