@@ -7,6 +7,7 @@ namespace spk {
 namespace k {
 
 constexpr int kDictChunk = kThreads;   // block rows per chunk: one per thread
+constexpr int kDictG3 = 9;             // 3x3 blocks whose loads are in flight together in the product kernel
 constexpr int kDict2Wgs = 512;         // pipelined 2x2 product: workgroups of a large launch (two per CU, all co-resident; each pipelines its chunks)
 typedef int int2v __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
@@ -29,6 +30,7 @@ struct DictArgs {
     // bs = 3: two words per block, plane k = position k (16 bytes per block row)
     int64_t plane_off[kDictMaxK];
     int32_t strad;                 // 2x2: some field lies across the halves of its word (dict_field2)
+    int32_t u3l[9], u3r[9];        // 3x3, one field layout for all classes (DictDev::uniform3): shifts of dict_field3u
     int32_t uw[4];                 // 2x2, uniform field layout (DictDev::uniform): the widths of the four entries; uw[0] = 0: not uniform
 };
 
@@ -74,6 +76,21 @@ __device__ __forceinline__ int dict_field(u64 w0, u64 w1, int fd)
     const u64 w = (fd >> 16) ? w1 : w0;
     const int sh = fd & 255, wd = (fd >> 8) & 255;
     return (int)((long long)(w << (64 - sh - wd)) >> (64 - wd));
+}
+// 3x3 blocks, ONE field layout for every class (DictDev::uniform3 = SPLIT: which entries sit in the second word -- 1: 5..8,
+// 2: 4..8, 3: 4 and 6..8, whichever lets the widest need of any class per entry fit twice 64 bits; the 256^3 slabs: 3).
+// The word is a compile-time choice, the shifts are kernel arguments: field to the top of the word, then a sign-extending
+// shift of the high half -- two instructions where the per-class form takes a dozen.
+template <int SPLIT>
+__device__ __forceinline__ constexpr bool dict3_in_w1(int e)
+{
+    return SPLIT == 1 ? e >= 5 : SPLIT == 2 ? e >= 4 : (e == 4 || e >= 6);
+}
+template <int SPLIT>
+__device__ __forceinline__ int dict_field3u(u64 w0, u64 w1, const DictArgs &d, int e)
+{
+    const u64 w = dict3_in_w1<SPLIT>(e) ? w1 : w0;
+    return (int)((long long)(w << d.u3l[e]) >> 32) >> d.u3r[e];
 }
 // 2x2 blocks: the fields never straddle the two 32-bit halves of the block's word (set-up packs them so), and the
 // descriptor is laid out for the hardware's bit-field extract: fd = offset (bits 0-4) | width << 8 | (high half ? 1 << 31 : 0).
@@ -124,6 +141,10 @@ inline DictArgs dict_args(const DictDev &A, int *grid)
     d.codes = A.codes.p;
     d.zpad = A.zpad.p;
     d.strad = A.straddle ? 1 : 0;
+    for (int e = 0; e < 9; ++e) {
+        d.u3l[e] = A.u3l[e];
+        d.u3r[e] = A.u3r[e];
+    }
     for (int e = 0; e < 4; ++e) d.uw[e] = A.uniform ? A.uw[e] : 0;
     d.nbrows = A.nbrows;
     d.ntype = A.ntype;

@@ -163,6 +163,8 @@ struct DictDev {
     bool uniform = false;
     int32_t uw[4] = {1, 1, 1, 1};
     bool straddle = false;         // 2x2: some class has a field across the halves of its word (spk_dict.hpp)
+    int uniform3 = 0;              // 3x3: one field layout for all classes; 1..3 = which entries sit in the second word
+    int32_t u3l[9] = {}, u3r[9] = {};   // its shifts (dict_field3u)
     bool ok = false;
 };
 

@@ -27,7 +27,8 @@
 namespace spk {
 namespace k {
 
-template <int BS, bool ACC, bool RIDE, bool BT>
+// U3 (3x3 blocks only): 0 = per-class fields, 1..3 = one field layout for all classes (dict_field3u)
+template <int BS, bool ACC, bool RIDE, bool BT, int U3>
 __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const double *__restrict__ x, double *__restrict__ y,
                                                              const int32_t *__restrict__ bt_rowptr,
                                                              const int32_t *__restrict__ bt_colidx,
@@ -94,8 +95,10 @@ __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const d
         }
         const int len = tlen[tc];
         const int2 *te = tent + (size_t)tc * d.kmax;
-        // blocks whose loads are in flight together: a 2-D interior row whole (five 16-byte code loads + nine gathers of x)
-        constexpr int G = BS == 2 ? 10 : 3;
+        // blocks whose loads are in flight together: a 2-D interior row whole (five 16-byte code loads + nine gathers of x);
+        // 3x3: nine (a third of an interior row; measured on the 256 x 256 x 32 slab: 264 us with three, 244-259 with five,
+        // 224-229 with nine)
+        constexpr int G = BS == 2 ? 10 : kDictG3;
         for (int k0 = 0; k0 < len; k0 += G) {
             int2 e[G];
             u64 w0[G], w1[BS == 2 ? 1 : G];
@@ -133,7 +136,10 @@ __global__ __launch_bounds__(kThreads) void spmv_dict_kernel(DictArgs d, const d
                     for (int r = 0; r < BS; ++r)
 #pragma unroll
                         for (int j = 0; j < BS; ++j)
-                            s[r] += dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j], d.strad != 0) : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * xv[g][j];
+                            s[r] += dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j], d.strad != 0)
+                                                       : U3 ? dict_field3u<(U3 ? U3 : 1)>(w0[g], w1[BS == 2 ? 0 : g], d, r * BS + j)
+                                                            : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]),
+                                                cb[r * BS + j]) * xv[g][j];
                 }
             }
         }
@@ -322,9 +328,16 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
     // LDS: the tables; a launch with a rider needs the rider's scratch in block 0
     size_t lds = (size_t)A.lds_bytes;
     if (rider) lds = std::max(lds, sizeof(double) * (size_t)(kThreads + 4 * (kMaxNv + 2) + 4));
-#define SPK_LAUNCH_DICT(BS, ACC, RIDE, BTF)                                                                                     \
-    hipLaunchKernelGGL((spmv_dict_kernel<BS, ACC, RIDE, BTF>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,             \
+#define SPK_LAUNCH_DICT_U(BS, ACC, RIDE, BTF, U3)                                                                               \
+    hipLaunchKernelGGL((spmv_dict_kernel<BS, ACC, RIDE, BTF, U3>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,         \
                        bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
+#define SPK_LAUNCH_DICT(BS, ACC, RIDE, BTF)                                                                                     \
+    do {                                                                                                                        \
+        if (BS == 2 || A.uniform3 == 0) SPK_LAUNCH_DICT_U(BS, ACC, RIDE, BTF, 0);                                               \
+        else if (A.uniform3 == 1) SPK_LAUNCH_DICT_U(3, ACC, RIDE, BTF, 1);                                                      \
+        else if (A.uniform3 == 2) SPK_LAUNCH_DICT_U(3, ACC, RIDE, BTF, 2);                                                      \
+        else SPK_LAUNCH_DICT_U(3, ACC, RIDE, BTF, 3);                                                                           \
+    } while (0)
 #define SPK_DISPATCH_DICT(BS)                                                                                                   \
     if (bt) {                                                                                                                   \
         if (rider) fail(SPK_ERR_ARG, "spmv_dict: B^T rows and a rider in one launch");                                         \
@@ -358,6 +371,7 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
     else { SPK_DISPATCH_DICT(3) }
 #undef SPK_DISPATCH_DICT
 #undef SPK_LAUNCH_DICT
+#undef SPK_LAUNCH_DICT_U
 }
 
 // ---------------------------------------------------------------------------
@@ -365,7 +379,7 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
 // decoded exactly, rounded to single precision (= the float copy the other sweep kernels read), products rounded once
 // each, summed per row in block order = CSR order -- the same bits as the CSR sweep and the oracle's float loop.
 // ---------------------------------------------------------------------------
-template <int BS>
+template <int BS, int U3>
 __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArgs d, const float *__restrict__ d32, float omega,
                                                                          const float *__restrict__ x32,
                                                                          const float *__restrict__ yin, float *__restrict__ yout,
@@ -424,7 +438,10 @@ __global__ __launch_bounds__(kThreads) void jacobi_sweep_f32_dict_kernel(DictArg
                     for (int r = 0; r < BS; ++r)
 #pragma unroll
                         for (int j = 0; j < BS; ++j)
-                            s[r] = (s[r] + ((float)dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j], d.strad != 0) : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]), cb[r * BS + j]) * yv[g][j]));
+                            s[r] = (s[r] + ((float)dict_decode(BS == 2 ? dict_field2(w0[g], fb[r * BS + j], d.strad != 0)
+                                                                      : U3 ? dict_field3u<(U3 ? U3 : 1)>(w0[g], w1[BS == 2 ? 0 : g], d, r * BS + j)
+                                                                           : dict_field(w0[g], w1[BS == 2 ? 0 : g], fb[r * BS + j]),
+                                                               cb[r * BS + j]) * yv[g][j]));
                 }
             }
         }
@@ -442,12 +459,15 @@ void jacobi_sweep_f32_dict(const DictDev &A, const float *d32, float omega, cons
     if (A.nbrows == 0) return;
     int grid = 0;
     const DictArgs d = dict_args(A, &grid);
-    if (A.bs == 2)
-        hipLaunchKernelGGL((jacobi_sweep_f32_dict_kernel<2>), dim3(grid), dim3(kThreads), (size_t)A.lds_bytes, s, d, d32, omega, x32,
-                           yin, yout, done);
-    else
-        hipLaunchKernelGGL((jacobi_sweep_f32_dict_kernel<3>), dim3(grid), dim3(kThreads), (size_t)A.lds_bytes, s, d, d32, omega, x32,
-                           yin, yout, done);
+#define SPK_LAUNCH_SWEEP(BS, U3)                                                                                                \
+    hipLaunchKernelGGL((jacobi_sweep_f32_dict_kernel<BS, U3>), dim3(grid), dim3(kThreads), (size_t)A.lds_bytes, s, d, d32, omega, x32, \
+                       yin, yout, done)
+    if (A.bs == 2) SPK_LAUNCH_SWEEP(2, 0);
+    else if (A.uniform3 == 0) SPK_LAUNCH_SWEEP(3, 0);
+    else if (A.uniform3 == 1) SPK_LAUNCH_SWEEP(3, 1);
+    else if (A.uniform3 == 2) SPK_LAUNCH_SWEEP(3, 2);
+    else SPK_LAUNCH_SWEEP(3, 3);
+#undef SPK_LAUNCH_SWEEP
 }
 
 // ---------------------------------------------------------------------------

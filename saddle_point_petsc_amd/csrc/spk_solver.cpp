@@ -268,6 +268,30 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
                 for (int e = 0; e < 4; ++e) hfld[(size_t)cl * 4 + e] = (int32_t)f[e];
         }
     }
+    // 3x3: the same idea over the two words of a block; the entries of the second word are one of three fixed sets
+    D.uniform3 = 0;
+    if (bs == 3 && !getenv("SPK_DICT_NOUNIFORM")) {
+        int uw[9];
+        for (int e = 0; e < 9; ++e) {
+            uw[e] = 1;
+            for (int cl = 0; cl < ncls; ++cl) uw[e] = std::max(uw[e], hwid[(size_t)cl * 9 + e]);
+        }
+        for (int split = 1; split <= 3 && !D.uniform3; ++split) {
+            auto in_w1 = [&](int e) { return split == 1 ? e >= 5 : split == 2 ? e >= 4 : (e == 4 || e >= 6); };
+            int used[2] = {0, 0};
+            for (int e = 0; e < 9; ++e) used[in_w1(e) ? 1 : 0] += uw[e];
+            if (used[0] > 64 || used[1] > 64) continue;
+            D.uniform3 = split;
+            int sh[2] = {0, 0};
+            for (int e = 0; e < 9; ++e) {
+                const int wd = in_w1(e) ? 1 : 0;
+                for (int cl = 0; cl <= ncls; ++cl) hfld[(size_t)cl * 9 + e] = sh[wd] | (uw[e] << 8) | (wd << 16);
+                D.u3l[e] = 64 - sh[wd] - uw[e];
+                D.u3r[e] = 32 - uw[e];
+                sh[wd] += uw[e];
+            }
+        }
+    }
     D.straddle = false;
     for (int cl = 0; cl < ncls; ++cl) {
         int used[2] = {0, 0}, word = 0;
@@ -294,7 +318,7 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
             const int i = cl * bb + e;
             const double scale = hscale[(size_t)i];
             const int width = hwid[(size_t)i];
-            if (D.uniform) {
+            if (D.uniform || D.uniform3) {
                 hcls[(size_t)2 * i + 1] = scale;
                 continue;
             }
@@ -371,7 +395,7 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
         }
         fprintf(stderr, "[spk] row types + codes: %d block rows, %d types (<= %d blocks), %d classes of %d x %d (<= %d bits of codes per block), "
                         "%d B of LDS, %.1f B of codes per block row%s\n", nbr, ntype, kmax, ncls, bs, bs, wmax, lds_bytes, (double)D.code_bytes / nbr,
-                D.uniform ? ", one field layout for all classes" : "");
+                D.uniform || D.uniform3 ? ", one field layout for all classes" : "");
         fprintf(stderr, "[spk]   widest need per block entry:");
         for (int e = 0; e < bb; ++e) {
             int w = 1;

@@ -60,14 +60,17 @@ def test_dictionary_3d_grid(spk, oracle, monkeypatch):
         y = c.mult(x)
         c.pc_setup(spk.PC_JACOBI, 0, inner_sweeps=3, inner_omega=0.7)
         return c.spmv_info()["format"], c.spmv_models(), y, c.pc_apply(x)
+    monkeypatch.delenv("SPK_DICT_NOUNIFORM", raising=False)
     d = _with_format(monkeypatch, spk, None, A, run)
     b = _with_format(monkeypatch, spk, "bcsr", A, run)
-    assert d[0] == "dict3x3" and b[0] == "bcsr3x3"
+    monkeypatch.setenv("SPK_DICT_NOUNIFORM", "1")      # per-class bit fields (what a rougher matrix would get)
+    p = _with_format(monkeypatch, spk, None, A, run)
+    assert d[0] == "dict3x3" and b[0] == "bcsr3x3" and p[0] == "dict3x3"
     assert d[1]["patterns"] <= 343 and d[1]["blocks"] <= 128
     y_ref = oracle.spmv(A, x)
-    assert np.array_equal(d[2], y_ref) and np.array_equal(b[2], y_ref)
+    assert np.array_equal(d[2], y_ref) and np.array_equal(b[2], y_ref) and np.array_equal(p[2], y_ref)
     z_ref = oracle.pc_apply_inner(A, None, oracle.PC_JACOBI, 0, 3, 0.7, x)
-    assert np.array_equal(d[3], z_ref) and np.array_equal(b[3], z_ref)
+    assert np.array_equal(d[3], z_ref) and np.array_equal(b[3], z_ref) and np.array_equal(p[3], z_ref)
 
 
 def test_dictionary_fp32_sweeps_2d(spk, oracle, monkeypatch):
