@@ -428,6 +428,11 @@ void dict_hash_blocks(int bs, const double *v0, const double *v1, int64_t ldp, i
                       int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys, hipStream_t s);
 // cls[(id, e)] = {entry e of block rep_of_id[id], 1}; slot[q] -> class number; gexp / dmax: per (class, entry) the finest
 // bit and the largest magnitude of value - base (INT32_MAX / 0 before the call); *bad: a deviation that is not exact
+// spk_k_dict3.hip: the pipelined forms for 3x3 blocks (27-point row types, DictDev::uniform3); false: not applicable
+bool spmv_dict3(const DictDev &A, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done, hipStream_t s,
+                bool accumulate, const OffDiag *od, const GivensRider *rider);
+bool jacobi_sweep_f32_dict3(const DictDev &A, const float *d32, float omega, const float *x32, const float *yin, float *yout,
+                            const int32_t *done, hipStream_t s);
 void dict_class_stats(int bs, const double *v0, const double *v1, int64_t ldp, int64_t nblocks, const int32_t *rep_of_id, int nid,
                       const int32_t *slot2id, int32_t *slot, double *cls, int32_t *gexp, unsigned long long *dmax, int32_t *bad,
                       hipStream_t s);

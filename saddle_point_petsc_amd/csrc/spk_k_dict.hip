@@ -320,6 +320,7 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
         if (rider) givens_rider_alone(*rider, done, s);
         return;
     }
+    if (spmv_dict3(A, x, y, bt, lam, done, s, accumulate, odp, rider)) return;   // 27-point row types, one field layout: pipelined
     int grid = 0;
     const DictArgs d = dict_args(A, &grid);
     const OffDiag od = odp ? *odp : OffDiag{nullptr, nullptr, nullptr, nullptr};
@@ -457,6 +458,7 @@ void jacobi_sweep_f32_dict(const DictDev &A, const float *d32, float omega, cons
                            const int32_t *done, hipStream_t s)
 {
     if (A.nbrows == 0) return;
+    if (jacobi_sweep_f32_dict3(A, d32, omega, x32, yin, yout, done, s)) return;
     int grid = 0;
     const DictArgs d = dict_args(A, &grid);
 #define SPK_LAUNCH_SWEEP(BS, U3)                                                                                                \

@@ -65,6 +65,11 @@ def test_dictionary_3d_grid(spk, oracle, monkeypatch):
     b = _with_format(monkeypatch, spk, "bcsr", A, run)
     monkeypatch.setenv("SPK_DICT_NOUNIFORM", "1")      # per-class bit fields (what a rougher matrix would get)
     p = _with_format(monkeypatch, spk, None, A, run)
+    monkeypatch.delenv("SPK_DICT_NOUNIFORM", raising=False)
+    monkeypatch.setenv("SPK_DICT3_PIPELINE", "1")      # the pipelined kernels of systems beyond a million block rows, here
+    q = _with_format(monkeypatch, spk, None, A, run)
+    monkeypatch.delenv("SPK_DICT3_PIPELINE", raising=False)
+    assert q[0] == "dict3x3" and np.array_equal(q[2], d[2]) and np.array_equal(q[3], d[3])
     assert d[0] == "dict3x3" and b[0] == "bcsr3x3" and p[0] == "dict3x3"
     assert d[1]["patterns"] <= 343 and d[1]["blocks"] <= 128
     y_ref = oracle.spmv(A, x)
