@@ -408,7 +408,9 @@ def main():
     byte_models = {k_: (models[k_ + "_bytes"] + extra if models[k_ + "_bytes"] else None) for k_ in ("csr", "blocked", "dict")}
     rates = {k_: (v / (loop_ms * 1e-3) / 1e9 if v else None) for k_, v in byte_models.items()}
     kernel_names = {"csr": "spmv_stream_kernel", "bcsr2x2": "spmv_bcsr_kernel", "bcsr3x3": "spmv_bcsr3_kernel",
-                    "dict2x2": "spmv_dict_kernel<2", "dict3x3": "spmv_dict_kernel<3"}
+                    # (row types of the 9-point / 27-point stencils take the pipelined kernels -- 3x3 from 2^20 block rows --
+                    # other shapes spmv_dict_kernel<2 | 3, ..>: profiles/*_kernel_stats_*.csv name the one that ran)
+                    "dict2x2": "spmv_dict2_kernel", "dict3x3": "spmv_dict3_kernel | spmv_dict_kernel<3>"}
     out = {
         "metric": METRIC,
         "value": its_per_s,
@@ -457,9 +459,9 @@ def main():
         # (`frac` = achieved / peak); the CSR-algorithmic figure of SURVEY 8(d) and the blocked layout's are beside it.
         "roofline": {"bound": "hbm",
                      "kernel": kernel_names[spi["format"]]
-                               + ("<.., ACC=true, RIDE=true[, BT=false]>: y += A x, as launched by the fused Schur iteration "
+                               + (" <ACC=true, RIDE=true, BT=false, ..>: y += A x, as launched by the fused Schur iteration "
                                   "(Givens rider in workgroup 0)" if in_solver_acc
-                                  else "<.., ACC=false, RIDE=true[, BT=false]>: y = A x, as launched by the iteration"),
+                                  else " <ACC=false, RIDE=true, BT=false, ..>: y = A x, as launched by the iteration"),
                      "format": spi["format"], "ms": loop_ms,
                      "achieved": min(loop_gbps, loop_layout_gbps), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": min(loop_gbps, loop_layout_gbps) / HBM_PEAK_GBS,

@@ -11,11 +11,12 @@
 //     in REGISTERS (31 x double2 = 124 VGPRs; 512-thread workgroups, two waves per SIMD) -- VecMDot is a register dot
 //     product and a reduction, VecMAXPY touches no memory at all;
 //   * the matrix is the "row types + deviation codes" layout (spk_dict.hpp): ~100 B per block row out of the L2;
-//   * per iteration the workgroups meet twice: (a) the inner products -- every workgroup publishes its partial sums and
-//     every workgroup reads and adds ALL of them in one fixed order (an all-to-all of <= 40 doubles x 256; values are their
-//     own arrival flags, the buffer is armed with a sentinel once per cycle), so all workgroups hold the same bits and run
-//     the same scalar work (Hessenberg column, Givens rotation, KSPConvergedDefault) redundantly -- no broadcast, no
-//     second hop; (b) the product: a workgroup stores its rows of z~ = M^-1 w' write-through into Z_{j+1} (armed with the
+//   * per iteration the workgroups meet twice: (a) the inner products -- every workgroup publishes its partial sums
+//     (values are their own arrival flags, the buffer is armed with a sentinel once per cycle); value v is added up, in
+//     one fixed order, by one workgroup of every group of 32 (an XCD's) and its total published to that group; every
+//     workgroup reads the <= 40 totals of its group, so all workgroups hold the same bits and run the same scalar work
+//     (Hessenberg column, Givens rotation, KSPConvergedDefault) redundantly.  (First form of this round: every workgroup
+//     read all 256 x 40 partials itself -- one hop, but 16 MB through the fabric per iteration: 5.8 us.)  (b) the product: a workgroup stores its rows of z~ = M^-1 w' write-through into Z_{j+1} (armed with the
 //     sentinel), its neighbours gather them with polling loads.  ||w'||^2 rides in the NEXT iteration's all-to-all.
 // Same algorithm as the default form (classical Gram-Schmidt, two reductions per iteration, un-normalised basis with one
 // scale factor per vector: include/spk.h, SPK_ITER_UNNORM); products of the A block bit-identical to the CSR loop.
@@ -126,7 +127,7 @@ struct ResArgs {
     const double *dinv, *bd;
     int64_t ldb;
     const double *shat, *gram;
-    double *P;             // all-to-all buffer, (mk + 1) x kResLd x kResG, armed
+    double *P;             // partial sums (mk + 1) x kResLd x kResG, then the groups' totals (mk + 1) x 8 x kResLd; armed
     KrylovArrays ka;
     double *sc_out;        // scale factors of the un-normalised basis (krylov_cycle_end)
     int32_t *err;
@@ -149,14 +150,13 @@ struct ResArgs {
 #endif
 
 constexpr int kResPass = 20;      // inner products reduced per pass through the LDS staging
-constexpr int kResMaxVals = 40;   // nv + m + 1 <= 30 + 8 + 1
+static_assert(kResLd >= 40, "an exchange carries nv + m + 1 <= 30 + 8 + 1 values");
 
 // NP: planes of B D a thread holds (0: K = A; packed: m = 2 NP, dense: m = NP)
 template <int T, int NP>
 __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
 {
     constexpr int LDP = T + 8;                                   // row stride of the product staging (bank shift per row)
-    constexpr int MAXIT = (kResMaxVals * 32 + T - 1) / T;        // all-to-all items (value, chunk of 8 workgroups) per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS: matrix tables | code planes of this workgroup's rows | product staging | scalar work space
     u64 *cwd = reinterpret_cast<u64 *>(smem + a.tab_bytes);        // kmax x T: the code word of every block of this workgroup's rows
@@ -229,7 +229,6 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
     const int32_t *fl = reinterpret_cast<const int32_t *>(smem + a.d.fld_off);
     const int len = active ? tlen[tid] : 0;
     const int2 *te = tent + (size_t)tid * a.d.kmax;
-    const int nch = (a.G + 7) / 8;
     __syncthreads();
 
     double nrmp = 0.0;   // this thread's share of ||w'||^2 of the previous iteration
@@ -296,55 +295,64 @@ __global__ __launch_bounds__(T) void cycle_resident_kernel(ResArgs a)
             if (s0 == 0) RES_STAMP(11);
         }
         RES_STAMP(1);
-        // ---- (b) every workgroup reads ALL partials and adds them in ONE order: the same bits everywhere.  Work item =
-        // (value, chunk of 8 workgroups); all loads of a thread in flight together, asked again while a slot is still armed
+        // ---- (b) the sums over the workgroups, in two hops.  (Every workgroup reading ALL partials -- 256 x nvt x 256
+        // doubles = 16 MB per iteration through the fabric, the partials being written under system scope -- cost 5.8 us.)
+        //   b1: value v belongs to member v mod S of every GROUP of workgroups (wg mod 8: the workgroups of one XCD where the
+        //       launch covers the chip).  That member reads the G partials of v, one per thread, adds them in ONE fixed
+        //       order and publishes the total for its group -- eight workgroups form every total, all with the same bits;
+        //   b2: every workgroup reads the nvt totals of its own group.
         {
-            const int nitems = nvt * nch;
-            double v[MAXIT][8];
             const double *Pb = a.P + (size_t)loc * kResLd * kResG;
-            const unsigned long long t0 = wall_clock64();
-            bool miss;
-            do {
-                miss = false;
-#pragma unroll
-                for (int q = 0; q < MAXIT; ++q) {
-                    const int it = t + q * T;
-                    const int i = it / nch, c = it - i * nch;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int g = 8 * c + u;
-                        v[q][u] = (it < nitems && g < a.G) ? peek(Pb + (size_t)i * kResG + g) : 0.0;
+            const int NG = a.G >= 64 ? 8 : 1, grp = wg % NG, mem = wg / NG, S = a.G / NG;
+            double *Tb = a.P + (size_t)(mk + 1) * kResLd * kResG + ((size_t)loc * 8 + grp) * kResLd;
+            if (mem < S) {
+                for (int v = mem; v < nvt; v += S) {
+                    double pv = 0.0;
+                    if (t < a.G) {
+                        const unsigned long long t0 = wall_clock64();
+                        for (;;) {
+                            pv = peek(Pb + (size_t)v * kResG + t);
+                            if (!is_sentinel(pv)) break;
+                            if (res_timed_out(t0, a.ticks) || flag[0]) {
+                                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                flag[0] = 1;
+                                pv = 0.0;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
                     }
+                    if (t < kResG) prod[t] = pv;
+                    bar_lds();
+                    if (t < 32) {
+                        double acc = 0.0;
+                        for (int j = t; j < a.G; j += 32) acc += prod[j];
+                        acc += __shfl_xor(acc, 16, kWave);
+                        acc += __shfl_xor(acc, 8, kWave);
+                        acc += __shfl_xor(acc, 4, kWave);
+                        acc += __shfl_xor(acc, 2, kWave);
+                        acc += __shfl_xor(acc, 1, kWave);
+                        if (t == 0) publish(Tb + v, acc);
+                    }
+                    bar_lds();
                 }
-#pragma unroll
-                for (int q = 0; q < MAXIT; ++q)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) miss = miss || is_sentinel(v[q][u]);
-                if (miss) {
+            }
+            if (t < nvt) {
+                const unsigned long long t0 = wall_clock64();
+                double tv;
+                for (;;) {
+                    tv = peek(Tb + t);
+                    if (!is_sentinel(tv)) break;
                     if (res_timed_out(t0, a.ticks) || flag[0]) {
                         __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         flag[0] = 1;
+                        tv = 0.0;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-            } while (miss);
-#pragma unroll
-            for (int q = 0; q < MAXIT; ++q) {
-                const int it = t + q * T;
-                if (it < nitems) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += v[q][u];
-                    prod[it] = acc;   // [value][chunk]
-                }
+                dots[t] = tv;
             }
-        }
-        bar_lds();
-        if (t < nvt) {
-            double s = 0.0;
-            for (int c = 0; c < nch; ++c) s += prod[t * nch + c];
-            dots[t] = s;
         }
         bar_lds();
         if (a.ar.P > 1) {
@@ -698,7 +706,7 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
     const size_t lds = resident_lds_bytes(A, T);
     // arm: the all-to-all buffer of this cycle and the rows of Z the product gathers
     {
-        const int64_t nP = (int64_t)(r.mk + 1) * kResG * kResLd;
+        const int64_t nP = (int64_t)(r.mk + 1) * (kResG + 8) * kResLd;   // the partials and the groups' totals
         const int64_t tot = std::max<int64_t>(nP, r.nl * (int64_t)(r.mk - 1));
         const int grid = (int)std::min<int64_t>((tot + kThreads - 1) / kThreads, 4096);
         hipLaunchKernelGGL(res_arm_kernel, dim3(std::max(grid, 1)), dim3(kThreads), 0, s, r.P, nP, r.Z, r.ld, r.nl, r.mk - 1, done);
@@ -761,7 +769,7 @@ bool cycle_resident(const DictDev &A, int num_cus, ResidentArgs r, const int32_t
     return true;
 }
 
-int64_t resident_scratch_doubles(int num_cus, int mk) { (void)num_cus; return (int64_t)(mk + 1) * kResG * kResLd; }
+int64_t resident_scratch_doubles(int num_cus, int mk) { (void)num_cus; return (int64_t)(mk + 1) * (kResG + 8) * kResLd; }
 
 }  // namespace k
 }  // namespace spk
