@@ -400,7 +400,27 @@ def main():
     head_path = args.inner_sweeps == 0 and ((saddle and planes > 0) or (not saddle and sz["n_local"] % 2 == 0))
     mrows = B.nrows if saddle else 0
     in_solver_acc = saddle and planes > 0            # the loop launches y += A x (else the plain product)
-    loop_ms = acc_ms if in_solver_acc else ride_ms
+    batch_ms = acc_ms if in_solver_acc else ride_ms      # a batch of back-to-back launches, HIP events around the batch
+    # The same launch timed WHERE IT RUNS: the kernel's own start / stop time stamps (hipExtLaunchKernelGGL events on the
+    # solver's stream) of every product launch of the iterations of one more solve over whole restart cycles -- behind the
+    # MAXPY pass, caches as that pass leaves them.  This is the figure the roofline claims; it is what
+    # `rocprofv3 --kernel-trace --stats` of the same command averages for that kernel (profiles/).  The resident form (and
+    # solves off the head path) launch no such product per iteration: there the batch figure stands in, and says so.
+    phase[0] = "product timing inside a solve"
+    ctx.time_products(4 * args.restart)
+    timed_solve(full_steps, **kw)
+    pt = ctx.product_timing()
+    # (Inside a solve a pair of stamps reads longer than the launch itself -- the start stamp is taken when the packet is
+    # picked up, before the previous kernel has drained.  The launches the device gates off at a solve's end show by how
+    # much: they are the same launch returning at once, whose cost alone is measured on a batch.  rocprofv3's figures for
+    # the in-solve launches agree with the corrected mean to ~2 %: tools/rocpd_product.py, profiles/*_product_in_solve.txt)
+    ctx.time_products(0)
+    stamp_offset_ms = 0.0
+    if pt["gated"] >= 1:
+        gated_batch_ms = ctx.time_kernel("spmv_gated", 0, 20, args.spmv_reps)
+        stamp_offset_ms = max(0.0, pt["gated_mean_ms"] - gated_batch_ms)
+    in_solve = pt["launches"] >= min(args.restart, 8)
+    loop_ms = max(pt["mean_ms"] - stamp_offset_ms, batch_ms) if in_solve else batch_ms
     loop_alg = alg_bytes + (8 * sz["n_local"] if in_solver_acc else 0)
     loop_layout = spi["layout_bytes"] + (8 * sz["n_local"] if in_solver_acc else 0)
     loop_gbps, loop_layout_gbps = loop_alg / (loop_ms * 1e-3) / 1e9, loop_layout / (loop_ms * 1e-3) / 1e9
@@ -463,6 +483,13 @@ def main():
                                   "(Givens rider in workgroup 0)" if in_solver_acc
                                   else " <ACC=false, RIDE=true, BT=false, ..>: y = A x, as launched by the iteration"),
                      "format": spi["format"], "ms": loop_ms,
+                     "ms_source": (f"mean of {pt['launches']} launches inside a solve of {full_steps} iterations: the kernel's own "
+                                   f"start/stop stamps as HIP events on the solver's stream ({pt['mean_ms'] * 1e3:.2f} us; median "
+                                   f"{pt['median_ms'] * 1e3:.2f}, {pt['min_ms'] * 1e3:.2f} .. {pt['max_ms'] * 1e3:.2f}) less the offset of such "
+                                   f"a pair, read off the {pt['gated']} launches the device had gated off ({stamp_offset_ms * 1e3:.2f} us)" if in_solve else
+                                   f"batch of {args.spmv_reps} back-to-back launches, HIP events around the batch (this solve launches "
+                                   "no product per iteration)"),
+                     "ms_back_to_back": batch_ms,
                      "achieved": min(loop_gbps, loop_layout_gbps), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": min(loop_gbps, loop_layout_gbps) / HBM_PEAK_GBS,
                      "byte_models": {"csr_algorithmic": byte_models["csr"], "blocked_layout": byte_models["blocked"],

@@ -321,7 +321,7 @@ int spk_kernel_maxpy(spk_ctx *ctx, int64_t n, int32_t nv, const double *a, const
  * x is a deterministic fill sin(0.37 i). */
 int spk_time_spmv(spk_ctx *ctx, int warmup, int reps, double *ms_per_launch);
 /* Generic form for the other kernels of an iteration (tuning / profiles):
- * which = "spmv" | "spmv_bcsr" | "spmv_bcsr3" | "spmv_dict" | "spmv_acc" | "spmv_ride" | "mult" | "pc" | "mdot" | "maxpy" | "maxpy_nonorm" | "scale" | "wide_dot" |
+ * which = "spmv" | "spmv_bcsr" | "spmv_bcsr3" | "spmv_dict" | "spmv_acc" | "spmv_ride" | "spmv_gated" | "mult" | "pc" | "mdot" | "maxpy" | "maxpy_nonorm" | "scale" | "wide_dot" |
  * "bt_update"; nv = vectors for mdot/maxpy.  Needs operators (and pc_setup for
  * "pc"); allocates its own scratch vectors. */
 int spk_time_kernel(spk_ctx *ctx, const char *which, int nv, int warmup, int reps,
@@ -339,6 +339,18 @@ int spk_debug_finish_timeout(spk_ctx *ctx, int timeout_ms);
  * in the MIDDLE of a cycle with SPK_ERR_HIP -- what a lost workgroup would cause -- so that tests can check that the context
  * stays usable afterwards. */
 int spk_debug_set_wait_bound(spk_ctx *ctx, uint32_t ticks);
+
+/* Measurement hook (bench.py's roofline): with max_launches > 0 the next solves take the kernel's OWN start and stop time
+ * stamps (hipExtLaunchKernelGGL) of each product launch of their ITERATIONS (y (+)= A x with the Givens rider in the
+ * launch -- the kernel the roofline names) into a pair of HIP events on the solver's stream, up to max_launches of them; 0
+ * switches it off.  spk_get_product_timing waits for the stream and returns their count and the mean / median / shortest /
+ * longest duration in ms: the kernel as it runs inside a solve -- behind the MAXPY pass, with the caches in the state that
+ * pass leaves -- not a batch of back-to-back repetitions; what `rocprofv3 --kernel-trace --stats` averages for it.
+ * Launches shorter than half the median (gated off by the device: the iterations enqueued ahead of a solve's end) are left
+ * out and reported apart (gated, gated_mean_ms).  (The resident form launches no product per iteration: count 0.) */
+int spk_debug_time_products(spk_ctx *ctx, int32_t max_launches);
+int spk_get_product_timing(spk_ctx *ctx, int32_t *launches, double *mean_ms, double *median_ms, double *min_ms, double *max_ms,
+                           int32_t *gated, double *gated_mean_ms);
 
 /* ---- host-only helpers: row-slab partition and halo plan ------------------ */
 /* (callable without a GPU; used by the multi-rank CPU tests) */

@@ -137,6 +137,8 @@ def _load():
     L.spk_debug_peer_allreduce_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_int, f64p, f64p]
     L.spk_debug_finish_timeout.argtypes = [vp, C.c_int]
     L.spk_debug_set_wait_bound.argtypes = [vp, C.c_uint32]
+    L.spk_debug_time_products.argtypes = [vp, C.c_int32]
+    L.spk_get_product_timing.argtypes = [vp, C.POINTER(C.c_int32)] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.spk_set_block.argtypes = [vp, C.c_int, i64, i32, i64, i32p, i32p, f64p]
     L.spk_pc_setup.argtypes = [vp, C.c_int, C.c_int]
     L.spk_pc_set_inner.argtypes = [vp, C.c_int, C.c_double]

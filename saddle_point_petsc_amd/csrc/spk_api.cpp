@@ -1,6 +1,7 @@
 // spk_api.cpp -- the extern "C" surface declared in include/spk.h.
 // Argument checks, error capture (exceptions never cross the ABI), staging of
 // host vectors.  The work is in spk_solver.cpp / spk_k_*.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +109,7 @@ int spk_destroy(spk_ctx *c)
         if (i == 0 && c->state_ev) (void)hipEventDestroy(c->state_ev);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
     }
+    for (hipEvent_t e : c->tp_ev) (void)hipEventDestroy(e);
     delete c;  // DevBuf destructors free device memory
     if (s) (void)hipStreamDestroy(s);
     return SPK_OK;
@@ -439,6 +441,65 @@ int spk_debug_set_wait_bound(spk_ctx *c, uint32_t ticks)
     return SPK_OK;
 }
 
+int spk_debug_time_products(spk_ctx *c, int32_t max_launches)
+{
+    SPK_TRY(c)
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    c->tp_used = 0;
+    c->time_products = max_launches > 0;
+    const size_t want = max_launches > 0 ? 2 * (size_t)max_launches : 0;
+    while (c->tp_ev.size() < want) {
+        hipEvent_t e;
+        SPK_HIP(hipEventCreate(&e));
+        c->tp_ev.push_back(e);
+    }
+    SPK_CATCH(c)
+}
+
+int spk_get_product_timing(spk_ctx *c, int32_t *launches, double *mean_ms, double *median_ms, double *min_ms, double *max_ms,
+                           int32_t *gated, double *gated_mean_ms)
+{
+    SPK_TRY(c)
+    SPK_HIP(hipStreamSynchronize(c->stream));
+    std::vector<float> t;
+    for (size_t i = 0; i + 1 < c->tp_used; i += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->tp_ev[i], c->tp_ev[i + 1]) != hipSuccess) {   // (a launch that took no stamps: an
+            (void)hipGetLastError();                                                   // empty rank runs the rider alone)
+            continue;
+        }
+        t.push_back(ms);
+    }
+    std::sort(t.begin(), t.end());
+    // (launches the device had gated off -- the iterations the host enqueues ahead of a solve's end return at once -- are
+    // not the kernel at work: anything shorter than half the median is left out of the mean and the count)
+    const double med = t.empty() ? 0.0 : t[t.size() / 2];
+    double sum = 0.0;
+    size_t used = 0;
+    double lo = 0.0;
+    for (float v : t)
+        if (v >= 0.5 * med) {
+            if (!used) lo = v;
+            sum += v;
+            ++used;
+        }
+    double gsum = 0.0;
+    size_t ng = 0;
+    for (float v : t)
+        if (v < 0.5 * med) {
+            gsum += v;
+            ++ng;
+        }
+    if (gated) *gated = (int32_t)ng;
+    if (gated_mean_ms) *gated_mean_ms = ng ? gsum / (double)ng : 0.0;
+    if (launches) *launches = (int32_t)used;
+    if (mean_ms) *mean_ms = used ? sum / (double)used : 0.0;
+    if (median_ms) *median_ms = med;
+    if (min_ms) *min_ms = lo;
+    if (max_ms) *max_ms = t.empty() ? 0.0 : t.back();
+    SPK_CATCH(c)
+}
+
 int spk_vec_create(spk_ctx *c, int64_t n, double **dev)
 {
     SPK_TRY(c)
@@ -572,6 +633,12 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
         else if (w == "spmv_bcsr3") { if (!c->Ab3.ok) spk::fail(SPK_ERR_STATE, "no 3x3-blocked copy"); spk::k::spmv_bcsr3(c->Ab3, x, y, nullptr, nullptr, nullptr, s); }
         else if (w == "spmv_dict") { if (!c->Adict.ok) spk::fail(SPK_ERR_STATE, "no row-type layout"); spk::k::spmv_dict(c->Adict, x, y, nullptr, nullptr, nullptr, s); }
         else if (w == "spmv_bcsr") { if (!c->Ab.ok) spk::fail(SPK_ERR_STATE, "no 2x2-blocked copy"); spk::k::spmv_bcsr(c->Ab, x, y, nullptr, nullptr, nullptr, s); }
+        else if (w == "spmv_gated") {
+            // the iteration's product launch as the device gates it off (`done` set: every workgroup returns at once)
+            spk::k::GivensRider gr{c->ka, 0, c->small.p, c->small.p + 64, nullptr, nullptr, 0, spk::k::FinErr{nullptr, 0}, spk::k::PeerAR{}};
+            if (!c->kst.p) spk::fail(SPK_ERR_STATE, "spk_time_kernel: spmv_gated needs the state of a solve");
+            spk::a_mult(c, x, y, nullptr, nullptr, &c->kst.p->done, true, nullptr, &gr);
+        }
         else if (w == "spmv_acc" || w == "spmv_ride") {
             // y += A x (spmv_ride: y = A x) in the active format, as the default iteration launches it: with the Givens
             // rider in workgroup 0 once a solve has left its state behind (the rider finds `done` set and leaves)
@@ -590,7 +657,7 @@ int spk_time_kernel(spk_ctx *c, const char *which, int nv, int warmup, int reps,
         else if (w == "bt_update") { if (!c->have_B || !c->pc_ready) spk::fail(SPK_ERR_STATE, "no B / pc"); spk::k::bt_update(1, c->Bt, c->dinv.p, x, c->small.p + 200, y, nullptr, s); }
         else spk::fail(SPK_ERR_ARG, "spk_time_kernel: unknown kernel '%s'", which);
     };
-    if ((w == "spmv_acc" || w == "spmv_ride") && c->kst.p) {
+    if ((w == "spmv_acc" || w == "spmv_ride" || w == "spmv_gated") && c->kst.p) {
         const int32_t one = 1;   // (krylov_init of the next solve resets it)
         SPK_HIP(hipMemcpyAsync(&c->kst.p->done, &one, sizeof one, hipMemcpyHostToDevice, s));
     }

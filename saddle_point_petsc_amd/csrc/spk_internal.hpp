@@ -20,6 +20,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "../../include/spk.h"
 
 namespace spk {
@@ -428,6 +430,18 @@ void dict_hash_blocks(int bs, const double *v0, const double *v1, int64_t ldp, i
                       int32_t *rep, int32_t *slot, int32_t *ctl, int maxkeys, hipStream_t s);
 // cls[(id, e)] = {entry e of block rep_of_id[id], 1}; slot[q] -> class number; gexp / dmax: per (class, entry) the finest
 // bit and the largest magnitude of value - base (INT32_MAX / 0 before the call); *bad: a deviation that is not exact
+// Measurement (spk_debug_time_products): a product launch takes the kernel's OWN start / stop time stamps into a pair of events
+// (hipExtLaunchKernelGGL) when the calling thread has set them -- a_mult around the iteration's product launch
+struct LaunchTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+LaunchTimer &launch_timer();
+#define SPK_LAUNCH_PRODUCT(kern, grid, block, lds, stream, ...)                                                                 \
+    do {                                                                                                                        \
+        const spk::k::LaunchTimer &lt_ = spk::k::launch_timer();                                                                \
+        if (lt_.start) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), stream, lt_.start, lt_.stop, 0, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                                   \
+    } while (0)
 // spk_k_dict3.hip: the pipelined forms for 3x3 blocks (27-point row types, DictDev::uniform3); false: not applicable
 bool spmv_dict3(const DictDev &A, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done, hipStream_t s,
                 bool accumulate, const OffDiag *od, const GivensRider *rider);
@@ -817,6 +831,11 @@ struct spk_ctx {
     spk::DevBuf<double> small;     // reduced scalars (256 doubles)
     spk::DevBuf<int32_t> errw;     // sticky device-side execution-error word (Finish::err)
     uint32_t fin_ticks = 400000000u;
+    // measurement (spk_debug_time_products): HIP events on the solver's stream around the product launches of the
+    // iterations (the launch with the Givens rider), read by spk_get_product_timing
+    bool time_products = false;
+    std::vector<hipEvent_t> tp_ev;   // pairs
+    size_t tp_used = 0;
     spk::k::Finish fin(double *out) { return spk::k::Finish{partials.p, out, spk::k::PeerAR{}, errw.p, fin_ticks}; }
     spk::k::Finish fin(double *out, const spk::k::PeerAR &ar) { return spk::k::Finish{partials.p, out, ar, errw.p, fin_ticks}; }
     // throws SPK_ERR_HIP when a device-side wait of a cross-workgroup reduction has timed out (call after a

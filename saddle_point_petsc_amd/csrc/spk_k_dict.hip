@@ -330,7 +330,7 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
     size_t lds = (size_t)A.lds_bytes;
     if (rider) lds = std::max(lds, sizeof(double) * (size_t)(kThreads + 4 * (kMaxNv + 2) + 4));
 #define SPK_LAUNCH_DICT_U(BS, ACC, RIDE, BTF, U3)                                                                               \
-    hipLaunchKernelGGL((spmv_dict_kernel<BS, ACC, RIDE, BTF, U3>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,         \
+    SPK_LAUNCH_PRODUCT((spmv_dict_kernel<BS, ACC, RIDE, BTF, U3>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,        \
                        bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
 #define SPK_LAUNCH_DICT(BS, ACC, RIDE, BTF)                                                                                     \
     do {                                                                                                                        \
@@ -358,11 +358,11 @@ void spmv_dict(const DictDev &A, const double *x, double *y, const CsrDev *bt, c
 #define SPK_LAUNCH_DICT(BS_, ACC, RIDE, BTF)                                                                                    \
     do {                                                                                                                        \
         if (A.uniform)                                                                                                          \
-            hipLaunchKernelGGL((spmv_dict2_kernel<ACC, RIDE, BTF, 9, true>), dim3(grid + nride), dim3(kThreads), lds, s, d, x,  \
+            SPK_LAUNCH_PRODUCT((spmv_dict2_kernel<ACC, RIDE, BTF, 9, true>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, \
                                y, bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od,  \
                                done, gr);                                                                                       \
         else                                                                                                                    \
-            hipLaunchKernelGGL((spmv_dict2_kernel<ACC, RIDE, BTF, 9, false>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, \
+            SPK_LAUNCH_PRODUCT((spmv_dict2_kernel<ACC, RIDE, BTF, 9, false>), dim3(grid + nride), dim3(kThreads), lds, s, d, x,\
                                y, bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od,  \
                                done, gr);                                                                                       \
     } while (0)

@@ -193,7 +193,7 @@ bool spmv_dict3(const DictDev &A, const double *x, double *y, const CsrDev *bt, 
     size_t lds = (size_t)A.lds_bytes;
     if (rider) lds = std::max(lds, sizeof(double) * (size_t)(kThreads + 4 * (kMaxNv + 2) + 4));
 #define SPK_L3U(ACC, RIDE, BTF, U3)                                                                                             \
-    hipLaunchKernelGGL((spmv_dict3_kernel<ACC, RIDE, BTF, U3>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,            \
+    SPK_LAUNCH_PRODUCT((spmv_dict3_kernel<ACC, RIDE, BTF, U3>), dim3(grid + nride), dim3(kThreads), lds, s, d, x, y,           \
                        bt ? bt->rowptr.p : nullptr, bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
 #define SPK_L3(ACC, RIDE, BTF)                                                                                                  \
     do {                                                                                                                        \

@@ -141,11 +141,11 @@ void spmv(const CsrDev &A, const double *x, double *y, const CsrDev *bt, const d
     const OffDiag o = od ? *od : OffDiag{nullptr, nullptr, nullptr, nullptr};
     const GivensRider gr = rider ? *rider : no_rider();
     if (rider)
-        hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads, true>), dim3(tpx * 8 + 1), dim3(kThreads), 0, s,
+        SPK_LAUNCH_PRODUCT((spmv_stream_kernel<false, kCsrTile, kThreads, true>), dim3(tpx * 8 + 1), dim3(kThreads), 0, s,
                            A.rowptr.p, A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
                            bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, o, done, gr);
     else
-        hipLaunchKernelGGL((spmv_stream_kernel<false, kCsrTile, kThreads, false>), dim3(tpx * 8), dim3(kThreads), 0, s,
+        SPK_LAUNCH_PRODUCT((spmv_stream_kernel<false, kCsrTile, kThreads, false>), dim3(tpx * 8), dim3(kThreads), 0, s,
                            A.rowptr.p, A.colidx.p, A.val.p, A.tile_row.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,
                            bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, accumulate ? 1 : 0, o, done, gr);
 }
@@ -319,7 +319,7 @@ void spmv_bcsr(const BcsrDev &A, const double *x, double *y, const CsrDev *bt, c
     // non-temporal loads on the matrix planes (read once per SpMV): 70.7 -> 61.3 us in the same run
     // (the rider is a template flag: the plain product keeps its registers and its 16 KB of LDS)
 #define SPK_LAUNCH_BCSR(ACC, RIDE, BTF)                                                                                         \
-    hipLaunchKernelGGL((spmv_bcsr_kernel<true, ACC, RIDE, BTF>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
+    SPK_LAUNCH_PRODUCT((spmv_bcsr_kernel<true, ACC, RIDE, BTF>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
                        A.vtop.p, A.vbot.p, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,                \
                        bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
     if (bt) {   // (MatMult on the nest operator: never the iteration's launch, no rider)
@@ -466,7 +466,7 @@ void spmv_bcsr3(const Bcsr3Dev &A, const double *x, double *y, const CsrDev *bt,
     const GivensRider gr = rider ? *rider : no_rider();
     const int nride = rider ? 1 : 0;
 #define SPK_LAUNCH_B3(ACC, RIDE)                                                                                          \
-    hipLaunchKernelGGL((spmv_bcsr3_kernel<ACC, RIDE>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
+    SPK_LAUNCH_PRODUCT((spmv_bcsr3_kernel<ACC, RIDE>), dim3(tpx * 8 + nride), dim3(kThreads), 0, s, A.browptr.p, A.bcol.p, \
                        A.v.p, A.ldp, A.tile_brow.p, A.ntiles, tpx, x, y, bt ? bt->rowptr.p : nullptr,                    \
                        bt ? bt->colidx.p : nullptr, bt ? bt->val.p : nullptr, lam, od, done, gr)
     if (accumulate) {

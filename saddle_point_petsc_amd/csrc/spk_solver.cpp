@@ -406,10 +406,26 @@ static void build_dict(spk_ctx *c, int bs, const int32_t *brp)
     }
 }
 
+namespace k {
+LaunchTimer &launch_timer()
+{
+    static thread_local LaunchTimer t;
+    return t;
+}
+}  // namespace k
+
 void a_mult(spk_ctx *c, const double *x, double *y, const CsrDev *bt, const double *lam, const int32_t *done, bool accumulate,
             const k::OffDiag *od, const k::GivensRider *rider)
 {
     hipStream_t s = c->stream;
+    // (bench.py's roofline: the iteration's product launches timed where they run, inside a solve)
+    // the kernel's own start / stop time stamps go into a pair of events (SPK_LAUNCH_PRODUCT)
+    const bool timed = c->time_products && rider && c->tp_used + 2 <= c->tp_ev.size();
+    struct Timed {
+        spk_ctx *c; bool on;
+        Timed(spk_ctx *c_, bool on_) : c(c_), on(on_) { if (on) k::launch_timer() = k::LaunchTimer{c->tp_ev[c->tp_used], c->tp_ev[c->tp_used + 1]}; }
+        ~Timed() { if (on) { k::launch_timer() = k::LaunchTimer{}; c->tp_used += 2; } }
+    } timer(c, timed);
     if (c->spmv_format != 0 && c->Adict.ok) k::spmv_dict(c->Adict, x, y, bt, lam, done, s, accumulate, od, rider);
     else if (c->spmv_format == 2) k::spmv_bcsr3(c->Ab3, x, y, bt, lam, done, s, accumulate, od, rider);
     else if (c->spmv_format == 1) k::spmv_bcsr(c->Ab, x, y, bt, lam, done, s, accumulate, od, rider);

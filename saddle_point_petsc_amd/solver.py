@@ -161,6 +161,17 @@ class Context:
         """Test hook: a reduction with a partial that never arrives; raises SpkError (SPK_ERR_HIP)."""
         self._chk(lib.spk_debug_finish_timeout(self.h, timeout_ms))
 
+    def time_products(self, max_launches):
+        """HIP events around the product launches of the next solves' iterations (0: off); see include/spk.h"""
+        self._chk(lib.spk_debug_time_products(self.h, max_launches))
+
+    def product_timing(self):
+        n, ng, gm = C.c_int32(), C.c_int32(), C.c_double()
+        v = [C.c_double() for _ in range(4)]
+        self._chk(lib.spk_get_product_timing(self.h, C.byref(n), *[C.byref(x) for x in v], C.byref(ng), C.byref(gm)))
+        return dict(launches=n.value, mean_ms=v[0].value, median_ms=v[1].value, min_ms=v[2].value, max_ms=v[3].value,
+                    gated=ng.value, gated_mean_ms=gm.value)
+
     def debug_set_wait_bound(self, ticks=0):
         """Test hook: bound of the device-side waits in 100 MHz ticks (0: the default, 4 s)."""
         self._chk(lib.spk_debug_set_wait_bound(self.h, ticks))

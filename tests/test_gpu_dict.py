@@ -217,6 +217,32 @@ def test_dictionary_per_class_fields(spk, oracle, monkeypatch, mx, my):
     assert fu == fp and np.array_equal(iu0["history"], ip0["history"]) and np.array_equal(xu0, xp0)
 
 
+def test_product_launches_timed_inside_a_solve(spk, monkeypatch):
+    """spk_debug_time_products / spk_get_product_timing (bench.py's roofline): one pair of HIP events per product launch of
+    the iterations -- restart - 1 per cycle on the three-launch form, none on the resident form -- and nothing when off."""
+    A, f = spk.AssembleOperator_Laplace(64)
+    B, g = spk.AssembleOperator_Constraints(64)
+    rhs = np.concatenate([f, g])
+    with spk.Context(0) as c:
+        c.set_block(spk.BLOCK_A00, A)
+        c.set_block(spk.BLOCK_A10, B)
+        c.pc_setup(spk.PC_SCHUR, spk.SCHUR_FULL)
+        x0, i0 = c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=60, iteration_form=5)
+        c.time_products(200)
+        x1, i1 = c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=60, iteration_form=5)
+        pt = c.product_timing()
+        # (29 per cycle; the two the host had enqueued ahead of the solve's end return at once and may or may not fall
+        # below the cut on a system this small)
+        assert 2 * 29 <= pt["launches"] <= 2 * 29 + 2 and 0.0 < pt["min_ms"] <= pt["median_ms"] <= pt["max_ms"] < 5.0
+        assert np.array_equal(x0, x1) and np.array_equal(i0["history"], i1["history"])     # (timing changes nothing)
+        c.time_products(200)
+        c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=60, iteration_form=6)
+        assert c.product_timing()["launches"] == 0
+        c.time_products(0)
+        c.fgmres(rhs, rtol=0.0, abstol=0.0, max_it=60, iteration_form=5)
+        assert c.product_timing()["launches"] == 0
+
+
 def test_dictionary_row_slabs(spk, oracle, monkeypatch):
     """three logical ranks: every slab finds its own dictionary (rows at a cut lose their off-rank blocks to the halo
     part), the partitioned product equals the single-rank one bit for bit away from the cuts."""

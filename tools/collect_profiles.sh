@@ -21,6 +21,7 @@ python3 $R/bench.py --steps 60 --warmup 10 --dim 3 --grid 96 --no-cpu-baseline >
 python3 $R/bench.py --steps 60 --warmup 10 --dim 3 --grid 96 --constraints div3d --no-cpu-baseline > $out/${tag}_bench_3d_96_div3d.json 2> $out/bench_3d96d.err
 rocprofv3 --kernel-trace --stats -d /tmp/prof_d -o run -- python3 $R/bench.py --no-cpu-baseline > $out/${tag}_bench_default_under_rocprof.json 2> $out/rocprof_default.err
 python3 $R/tools/rocpd_stats.py /tmp/prof_d/run_results.db $out/${tag}_kernel_stats_bench_default.csv > $out/stats_default.txt
+python3 $R/tools/rocpd_product.py /tmp/prof_d/run_results.db > $out/${tag}_product_in_solve.txt 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o run -- python3 $R/bench.py --grid 1024 --grid-y 128 --no-cpu-baseline > $out/${tag}_bench_slab_1of8_under_rocprof.json 2> $out/rocprof_slab.err
 python3 $R/tools/rocpd_stats.py /tmp/prof_s/run_results.db $out/${tag}_kernel_stats_slab_1of8.csv > $out/stats_slab.txt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_j -o run -- python3 $R/bench.py --grid 256 --pc jacobi --no-cpu-baseline > $out/${tag}_bench_256_jacobi_under_rocprof.json 2> $out/rocprof_256.err
