@@ -373,6 +373,24 @@ def main():
     # the variant the fused Schur iteration launches: y += A x (y pre-loaded with B^T lambda): 8n more bytes
     acc_ms = ctx.time_kernel("spmv_acc", 0, 20, args.spmv_reps)
     ride_ms = ctx.time_kernel("spmv_ride", 0, 20, args.spmv_reps)   # y = A x with the rider: the Jacobi iteration's launch
+    # The same launch timed WHERE IT RUNS: the kernel's own start / stop time stamps (hipExtLaunchKernelGGL events on the
+    # solver's stream) of every product launch of the iterations of one more solve over whole restart cycles -- behind the
+    # MAXPY pass, caches as that pass leaves them.  This is the figure the roofline claims; it is what
+    # `rocprofv3 --kernel-trace --stats` of the same command averages for that kernel's launches inside the solves
+    # (tools/rocpd_product.py, profiles/*_product_in_solve.txt).  The resident form (and solves off the head path) launch no
+    # such product per iteration: there the batch figure stands in, and says so.
+    # (Inside a solve a pair of stamps reads longer than the launch itself -- the start stamp is taken when the packet is
+    # picked up, before the previous kernel has drained.  The launches the device gates off at a solve's end show by how
+    # much: they are the same launch returning at once, whose cost alone is measured on a batch.)
+    phase[0] = "product timing inside a solve"
+    ctx.time_products(4 * args.restart)
+    timed_solve(full_steps, **kw)
+    pt = ctx.product_timing()
+    ctx.time_products(0)
+    stamp_offset_ms = 0.0
+    if pt["gated"] >= 1:
+        gated_batch_ms = ctx.time_kernel("spmv_gated", 0, 20, args.spmv_reps)
+        stamp_offset_ms = max(0.0, pt["gated_mean_ms"] - gated_batch_ms)
     # per-rank diagnostics of the communicator, gathered to rank 0: an N-GPU line explains itself
     rank_info = [ctx.comm_info()]
     if dist is not None and world > 1:
@@ -401,24 +419,6 @@ def main():
     mrows = B.nrows if saddle else 0
     in_solver_acc = saddle and planes > 0            # the loop launches y += A x (else the plain product)
     batch_ms = acc_ms if in_solver_acc else ride_ms      # a batch of back-to-back launches, HIP events around the batch
-    # The same launch timed WHERE IT RUNS: the kernel's own start / stop time stamps (hipExtLaunchKernelGGL events on the
-    # solver's stream) of every product launch of the iterations of one more solve over whole restart cycles -- behind the
-    # MAXPY pass, caches as that pass leaves them.  This is the figure the roofline claims; it is what
-    # `rocprofv3 --kernel-trace --stats` of the same command averages for that kernel (profiles/).  The resident form (and
-    # solves off the head path) launch no such product per iteration: there the batch figure stands in, and says so.
-    phase[0] = "product timing inside a solve"
-    ctx.time_products(4 * args.restart)
-    timed_solve(full_steps, **kw)
-    pt = ctx.product_timing()
-    # (Inside a solve a pair of stamps reads longer than the launch itself -- the start stamp is taken when the packet is
-    # picked up, before the previous kernel has drained.  The launches the device gates off at a solve's end show by how
-    # much: they are the same launch returning at once, whose cost alone is measured on a batch.  rocprofv3's figures for
-    # the in-solve launches agree with the corrected mean to ~2 %: tools/rocpd_product.py, profiles/*_product_in_solve.txt)
-    ctx.time_products(0)
-    stamp_offset_ms = 0.0
-    if pt["gated"] >= 1:
-        gated_batch_ms = ctx.time_kernel("spmv_gated", 0, 20, args.spmv_reps)
-        stamp_offset_ms = max(0.0, pt["gated_mean_ms"] - gated_batch_ms)
     in_solve = pt["launches"] >= min(args.restart, 8)
     loop_ms = max(pt["mean_ms"] - stamp_offset_ms, batch_ms) if in_solve else batch_ms
     loop_alg = alg_bytes + (8 * sz["n_local"] if in_solver_acc else 0)
